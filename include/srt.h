@@ -1,0 +1,177 @@
+/*
+ * srt.h -- C ABI of libsrt.so, the MI355X (gfx950) trace loop for helpvisa/simple_raytracer.
+ *
+ * The reference (C#, MonoGame) has no plugin or FFI seam.  This ABI is the seam a maintainer
+ * adds: Game1.LoadContent stops spawning renderBlock threads (Game1.cs:161-175, 376-380) and
+ * instead hands the scene it built in Game1.Initialize (Game1.cs:96-144) to this library, which
+ * fills the same Color[] buffer (Game1.cs:157, PixelManagement.cs:8-23).  Every entry point
+ * names the reference code it stands in for.
+ *
+ * Conventions
+ *  - plain C, no C++ types or exceptions cross the boundary; every function returns 0
+ *    (SRT_OK) or a negative SRT_E_* code, and srt_last_error() describes the last failure;
+ *  - pointers passed in are caller-owned and only read during the call (scene arrays are
+ *    copied); output buffers are caller-owned;
+ *  - a context is bound to one HIP device and is not thread-safe: the caller serialises
+ *    calls, as the single UI thread of Game1 does;
+ *  - there is no CPU fallback: without a usable gfx950 device srt_create fails.
+ */
+#ifndef SRT_H
+#define SRT_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define SRT_VERSION 100
+
+enum {
+    SRT_OK = 0,
+    SRT_E_INVALID = -1,      /* bad argument */
+    SRT_E_NO_DEVICE = -2,    /* no usable HIP device / not gfx950 */
+    SRT_E_HIP = -3,          /* a HIP runtime call failed */
+    SRT_E_STATE = -4,        /* call sequence error (e.g. render before commit) */
+    SRT_E_REFERENCE = -5,    /* the reference program would throw for this configuration */
+    SRT_E_LIMIT = -6         /* a documented size limit is exceeded */
+};
+
+/* Which Surface the trace loop intersects, named after the reference object it reproduces. */
+enum {
+    /* GetRayColor(ray, nodeWorld, ...) as Game1.cs:293 calls it: the BVHNode tree built by the
+     * reference's own builder (RaytracingClasses.cs:346-426) and walked with BVHNode.hit /
+     * AABB.hit semantics (:428-442, :773-789).  A world holding a RectAxis is rejected with
+     * SRT_E_REFERENCE (RectAxis has no boundingBox override, :503-544; the reference builder
+     * dereferences its null bounds). */
+    SRT_WORLD_BVHNODE = 0,
+    /* GetRayColor(ray, world, ...): SurfaceList.hit semantics (RaytracingClasses.cs:298-316), the
+     * closest hit over every surface in insertion order, later surface winning an exact tie.
+     * The library answers this query through its own SAH BVH with padded boxes, which returns
+     * the same hit as the linear scan. */
+    SRT_WORLD_SURFACELIST = 1
+};
+
+/* Per-ray colour function (RaytracingOperations.cs), selected in the reference by editing Game1.cs:290-293. */
+enum {
+    SRT_MODE_COLOR = 0,      /* RayOperations.GetRayColor        RaytracingOperations.cs:75-195 */
+    SRT_MODE_NORMAL = 1,     /* RayOperations.GetRayNormalColor  RaytracingOperations.cs:11-21 */
+    SRT_MODE_DEPTH = 2,      /* RayOperations.GetRayDepthColor   RaytracingOperations.cs:24-35 */
+    SRT_MODE_LIGHTS = 3      /* RayOperations.GetLights          RaytracingOperations.cs:197-205 */
+};
+
+/* Output layout of a render. */
+enum {
+    SRT_LAYOUT_FRAME = 0,    /* row-major W*H, pixel (x,y) at x + y*W (PixelManagement.cs:22) */
+    SRT_LAYOUT_TILES = 1     /* this rank's tiles only, tile-major; see srt_render_params */
+};
+
+#define SRT_MAX_DEPTH 16      /* largest max_depth accepted */
+#define SRT_MAX_LIGHTS 4096
+
+/* Material after its constructor ran (clamped albedo / metalness / smoothness), RaytracingClasses.cs:221-262. 32 bytes. */
+typedef struct { float albedo[3]; float metalness; float smoothness; float emission[3]; } srt_material;
+/* PointLight after its constructor ran (brightness possibly rescaled), RaytracingClasses.cs:75-94,190-192. 28 bytes. */
+typedef struct { float position[3]; float brightness; float color[3]; } srt_point_light;
+
+typedef struct {
+    int32_t device;          /* HIP device ordinal */
+    int32_t reserved;
+} srt_config;
+
+/* Render settings: the hard-coded fields of Game1 (Game1.cs:41-43,78-79) plus the RNG seed
+ * (the reference seeds System.Random from entropy, Game1.cs:44,378) and the multi-GPU
+ * partition (the reference's row bands per thread, Game1.cs:376-380, become screen tiles
+ * per rank). */
+typedef struct {
+    int32_t  width, height;  /* full image, globalWidth / globalHeight */
+    int32_t  samples;        /* Game1.samples */
+    int32_t  max_depth;      /* Game1.maxDepth, 1..SRT_MAX_DEPTH */
+    float    color_clamp;    /* Game1.colorClamp, >= 0 */
+    uint32_t seed;
+    int32_t  mode;           /* SRT_MODE_* */
+    int32_t  layout;         /* SRT_LAYOUT_* */
+    int32_t  tile_w, tile_h; /* screen tile, multiples of 8; 0 = 32.  Only used with SRT_LAYOUT_TILES. */
+    int32_t  rank, world_size; /* tile t (row-major over the tile grid) belongs to rank t % world_size;
+                                  a rank's j-th tile (j = t / world_size) occupies pixels
+                                  [j*tile_w*tile_h, (j+1)*tile_w*tile_h) of its buffer, row-major inside the tile,
+                                  edge tiles padded.  world_size 0 or 1 = everything. */
+} srt_render_params;
+
+typedef struct {
+    uint64_t rays_path;      /* GetRayColor calls with depth >= 1: primary + bounce rays */
+    uint64_t rays_shadow;    /* shadow rays, RaytracingClasses.cs:174 */
+    uint64_t hit_nodes;      /* GetRayColor calls that hit a surface */
+    uint64_t box_tests;      /* BVH nodes whose box was tested   (only filled by srt_render_counted) */
+    uint64_t sphere_tests, tri_tests, rect_tests;   /* (only filled by srt_render_counted) */
+    double   kernel_ms;      /* duration of the last trace kernel, from HIP events on its stream */
+    double   build_ms;       /* host time of the last srt_commit_scene (BVH build + upload) */
+    uint32_t bvh_nodes;      /* nodes in the linearised BVH (32 bytes each) */
+    uint32_t bvh_depth;
+    uint32_t n_prims;
+    uint32_t reserved;
+} srt_stats;
+
+typedef struct srt_ctx srt_ctx;
+
+int  srt_version(void);
+
+/* Replaces nothing in the reference: owns the device-side copies of what Game1 keeps on the heap. */
+int  srt_create(const srt_config* cfg, srt_ctx** out);
+void srt_destroy(srt_ctx* ctx);
+/* Thread-local text of the last error of `ctx` (or of srt_create when ctx is NULL). */
+const char* srt_last_error(const srt_ctx* ctx);
+
+/* Camera.position / lowerLeftCorner / horizontal / vertical as its constructor computed them
+ * (RaytracingClasses.cs:34-50, 57-63); read by the ray generation of Game1.cs:283-287. */
+int  srt_set_camera(srt_ctx* ctx, const float position[3], const float lower_left[3], const float horizontal[3], const float vertical[3]);
+/* The Material objects referenced by the surfaces (RaytracingClasses.cs:221-262). */
+int  srt_set_materials(srt_ctx* ctx, const srt_material* materials, uint32_t n);
+/* world.surfaces entries of type Sphere (RaytracingClasses.cs:449-500, fields :497-499), structure of arrays. */
+int  srt_set_spheres(srt_ctx* ctx, const float* cx, const float* cy, const float* cz, const float* radius, const uint32_t* material, uint32_t n);
+/* world.surfaces entries of type RectAxis (RaytracingClasses.cs:503-544), structure of arrays. */
+int  srt_set_rects(srt_ctx* ctx, const float* x1, const float* x2, const float* y1, const float* y2, const float* k, const uint32_t* material, uint32_t n);
+/* world.surfaces entries of type Tri (RaytracingClasses.cs:547-680) as ModelLoader builds them
+ * (ModelLoader.cs:39-64): pos9 = A,B,C positions, nrm9 = their normals, 9 floats per triangle;
+ * flags bit0 = flipNormal, bit1 = blend (NULL = blend only, the loader's setting). */
+int  srt_set_triangles(srt_ctx* ctx, const float* pos9, const float* nrm9, const uint32_t* material, const uint8_t* flags, uint32_t n);
+/* lights.lights (LightList of PointLight, RaytracingClasses.cs:195-203; Game1.cs:140-144). */
+int  srt_set_lights(srt_ctx* ctx, const srt_point_light* lights, uint32_t n);
+/* world.Init() + new BVHNode(world) (Game1.cs:136-137): flattens the scene, builds and linearises the BVH
+ * (32-byte nodes) and uploads everything.  Insertion order of world.surfaces is taken to be
+ * triangles, spheres, rects -- the statement order of Game1.cs:112-134. */
+int  srt_commit_scene(srt_ctx* ctx, int world_kind);
+
+/* Replaces Parallel.For(0, N, startThread) + renderBlock + WritePixel (Game1.cs:165, 264-317;
+ * PixelManagement.cs:8-23).  Blocking; rgba_out is the Color[] buffer (packed R | G<<8 | B<<16 | A<<24)
+ * sized for the layout: width*height pixels for SRT_LAYOUT_FRAME, srt_local_pixels() for SRT_LAYOUT_TILES.
+ * All rows are rendered (the reference leaves the last height mod N rows black, Game1.cs:378). */
+int  srt_render(srt_ctx* ctx, const srt_render_params* p, uint32_t* rgba_out);
+/* Same, writing to device memory on the caller's HIP stream (hipStream_t passed as void*, NULL = the
+ * context's own stream) without synchronising: the host side of a multi-GPU job keeps the tiles on the
+ * device for the gather.  capacity_pixels is the size of d_rgba_out in pixels. */
+int  srt_render_device(srt_ctx* ctx, const srt_render_params* p, void* d_rgba_out, size_t capacity_pixels, void* hip_stream);
+/* srt_render with the event counters of srt_stats filled (a separately compiled, slower kernel). */
+int  srt_render_counted(srt_ctx* ctx, const srt_render_params* p, uint32_t* rgba_out);
+
+/* Replaces the threadArray[i].IsAlive polling of Game1.Update (Game1.cs:188-201): start a render,
+ * ask whether it is done, wait for it.  rgba_out must stay valid until done. */
+int  srt_render_async(srt_ctx* ctx, const srt_render_params* p, uint32_t* rgba_out);
+int  srt_poll(srt_ctx* ctx, int* done);
+int  srt_wait(srt_ctx* ctx);
+
+/* Counters of the last finished render of this context. */
+int  srt_get_stats(srt_ctx* ctx, srt_stats* out);
+
+/* Size in pixels of the buffer a rank renders into for these parameters (tile-major, padded tiles). */
+int64_t srt_local_pixels(const srt_render_params* p);
+/* Rank 0 of a multi-GPU job: scatter the gathered per-rank tile buffers (rank r's buffer at
+ * d_gathered + r*stride_pixels) into the row-major frame, i.e. what the shared Color[] of Game1.cs:157
+ * is for the reference's threads.  Device pointers; runs on hip_stream without synchronising. */
+int  srt_assemble_tiles(srt_ctx* ctx, const srt_render_params* p, const void* d_gathered, size_t stride_pixels, void* d_frame, void* hip_stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* SRT_H */

@@ -1,0 +1,225 @@
+"""ctypes binding of the CPU oracle (liborc.so).
+
+TEST INFRASTRUCTURE ONLY.  Import this from tests/, from the smoke check and from the
+cpu_baseline leg of bench.py -- never from the simple_raytracer_amd package.
+"""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB_PATH = os.path.join(_HERE, "liborc.so")
+
+WORLD_BVHNODE = 0
+WORLD_SURFACELIST = 1
+MODE_COLOR, MODE_NORMAL, MODE_DEPTH, MODE_LIGHTS = 0, 1, 2, 3
+
+
+class Material(C.Structure):
+    _fields_ = [("albedo", C.c_float * 3), ("metalness", C.c_float), ("smoothness", C.c_float), ("emission", C.c_float * 3)]
+
+
+class Sphere(C.Structure):
+    _fields_ = [("origin", C.c_float * 3), ("radius", C.c_float), ("material", C.c_int32)]
+
+
+class Rect(C.Structure):
+    _fields_ = [("x1", C.c_float), ("x2", C.c_float), ("y1", C.c_float), ("y2", C.c_float), ("k", C.c_float), ("material", C.c_int32)]
+
+
+class Tri(C.Structure):
+    _fields_ = [("pos", C.c_float * 9), ("nrm", C.c_float * 9), ("material", C.c_int32), ("flip", C.c_int32), ("blend", C.c_int32)]
+
+
+class Light(C.Structure):
+    _fields_ = [("position", C.c_float * 3), ("brightness", C.c_float), ("color", C.c_float * 3)]
+
+
+class Camera(C.Structure):
+    _fields_ = [("position", C.c_float * 3), ("lower_left", C.c_float * 3), ("horizontal", C.c_float * 3), ("vertical", C.c_float * 3)]
+
+
+class Params(C.Structure):
+    _fields_ = [("width", C.c_int32), ("height", C.c_int32), ("samples", C.c_int32), ("max_depth", C.c_int32),
+                ("color_clamp", C.c_float), ("seed", C.c_uint32), ("mode", C.c_int32), ("world_kind", C.c_int32),
+                ("threads", C.c_int32), ("drop_remainder_rows", C.c_int32),
+                ("x0", C.c_int32), ("y0", C.c_int32), ("x1", C.c_int32), ("y1", C.c_int32)]
+
+
+class Stats(C.Structure):
+    _fields_ = [("rays_path", C.c_uint64), ("rays_shadow", C.c_uint64), ("rays_redundant", C.c_uint64), ("box_tests", C.c_uint64),
+                ("sphere_tests", C.c_uint64), ("tri_tests", C.c_uint64), ("rect_tests", C.c_uint64), ("hit_nodes", C.c_uint64),
+                ("seconds", C.c_double), ("threads_used", C.c_int32)]
+
+
+def build(force=False):
+    """Compile liborc.so with the committed Makefile (g++ only)."""
+    if force or not os.path.exists(_LIB_PATH) or any(
+            os.path.getmtime(os.path.join(_HERE, f)) > os.path.getmtime(_LIB_PATH) for f in ("srt_oracle.cpp", "srt_oracle.h")):
+        subprocess.check_call(["make", "-C", _HERE, "-s"])
+
+
+_lib = None
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        if not os.path.exists(_LIB_PATH):
+            build()
+        L = C.CDLL(_LIB_PATH)
+        F3 = C.POINTER(C.c_float)
+        L.orc_scene_create.restype = C.c_void_p
+        L.orc_scene_create.argtypes = [C.POINTER(Material), C.c_int32, C.POINTER(Tri), C.c_int32, C.POINTER(Sphere), C.c_int32,
+                                       C.POINTER(Rect), C.c_int32, C.POINTER(Light), C.c_int32]
+        L.orc_scene_destroy.argtypes = [C.c_void_p]
+        L.orc_scene_bvh_nodes.argtypes = [C.c_void_p]
+        L.orc_scene_bvh_depth.argtypes = [C.c_void_p]
+        L.orc_scene_bvh_leaf_order.argtypes = [C.c_void_p, C.POINTER(C.c_int32), C.c_int32]
+        L.orc_render.argtypes = [C.c_void_p, C.POINTER(Camera), C.POINTER(Params), C.c_void_p, C.c_void_p, C.POINTER(Stats)]
+        L.orc_last_error.restype = C.c_char_p
+        L.orc_camera_ctor.argtypes = [F3, F3, C.c_float, C.c_float, C.POINTER(Camera)]
+        L.orc_material_ctor.argtypes = [F3, C.c_float, C.c_float, F3, C.POINTER(Material)]
+        L.orc_pointlight_ctor.argtypes = [F3, C.c_float, F3, C.POINTER(Light)]
+        for name, prim in (("orc_sphere_hit", Sphere), ("orc_rect_hit", Rect), ("orc_tri_hit", Tri)):
+            getattr(L, name).argtypes = [C.POINTER(prim), F3, F3, C.c_float, C.c_float, F3]
+        L.orc_aabb_hit.argtypes = [F3, F3, F3, F3]
+        L.orc_sky.argtypes = [F3, F3]
+        L.orc_depth_heuristic.argtypes = [C.c_int, C.c_float]
+        L.orc_pack_color.restype = C.c_uint32
+        L.orc_pack_color.argtypes = [C.c_float, C.c_float, C.c_float]
+        L.orc_rng_words.argtypes = [C.c_uint32] * 5 + [C.POINTER(C.c_uint32)]
+        L.orc_rng_next.argtypes = [C.c_uint32, C.c_int, C.c_int]
+        L.orc_random_vector.argtypes = [C.c_uint32] * 5 + [F3]
+        L.orc_hemisphere_vector.argtypes = [C.c_uint32] * 4 + [F3, F3]
+        L.orc_angle_between.restype = C.c_float
+        L.orc_angle_between.argtypes = [F3, F3]
+        L.orc_get_lights.argtypes = [C.c_void_p, C.c_int, F3, F3] + [C.c_uint32] * 4 + [F3]
+        L.orc_get_ray_color.argtypes = [C.c_void_p, C.c_int, F3, F3, C.c_int, C.c_float] + [C.c_uint32] * 3 + [F3]
+        _lib = L
+    return _lib
+
+
+def f3(v):
+    return (C.c_float * 3)(*[float(x) for x in v])
+
+
+def _arr(ctype, items):
+    n = len(items)
+    return ((ctype * n)(*items) if n else None), n
+
+
+def camera(origin, look_at, fov_deg, ratio):
+    out = Camera()
+    lib().orc_camera_ctor(f3(origin), f3(look_at), float(fov_deg), float(ratio), C.byref(out))
+    return out
+
+
+def material(albedo, metal, smooth, emission=(0, 0, 0)):
+    out = Material()
+    lib().orc_material_ctor(f3(albedo), float(metal), float(smooth), f3(emission), C.byref(out))
+    return out
+
+
+def point_light(origin, brightness, color=None):
+    out = Light()
+    lib().orc_pointlight_ctor(f3(origin), float(brightness), f3(color) if color is not None else None, C.byref(out))
+    return out
+
+
+def tris_from_arrays(pos9, nrm9, material_index=0, flip=False, blend=True):
+    """pos9 / nrm9: (n, 9) float32 arrays -> ctypes array of Tri (fast path for big meshes)."""
+    pos9 = np.ascontiguousarray(pos9, dtype=np.float32).reshape(-1, 9)
+    nrm9 = np.ascontiguousarray(nrm9, dtype=np.float32).reshape(-1, 9)
+    n = pos9.shape[0]
+    dt = np.dtype([("pos", np.float32, 9), ("nrm", np.float32, 9), ("material", np.int32), ("flip", np.int32), ("blend", np.int32)])
+    rec = np.zeros(n, dtype=dt)
+    rec["pos"], rec["nrm"] = pos9, nrm9
+    rec["material"] = material_index
+    rec["flip"], rec["blend"] = int(flip), int(blend)
+    assert dt.itemsize == C.sizeof(Tri)
+    return rec
+
+
+class Scene:
+    """world + lights as the reference's Game1.Initialize builds them (Game1.cs:96-144)."""
+
+    def __init__(self, materials, spheres=(), rects=(), tris=None, lights=()):
+        L = lib()
+        m, nm = _arr(Material, list(materials))
+        s, ns = _arr(Sphere, list(spheres))
+        r, nr = _arr(Rect, list(rects))
+        li, nl = _arr(Light, list(lights))
+        if tris is None:
+            t, nt = None, 0
+        elif isinstance(tris, np.ndarray):
+            self._tri_keepalive = np.ascontiguousarray(tris)
+            t, nt = self._tri_keepalive.ctypes.data_as(C.POINTER(Tri)), len(self._tri_keepalive)
+        else:
+            t, nt = _arr(Tri, list(tris))
+        self.n_prims = nt + ns + nr
+        self._h = L.orc_scene_create(m, nm, t, nt, s, ns, r, nr, li, nl)
+        if not self._h:
+            raise ValueError(L.orc_last_error().decode())
+
+    def __del__(self):
+        if getattr(self, "_h", None):
+            lib().orc_scene_destroy(self._h)
+            self._h = None
+
+    @property
+    def handle(self):
+        return self._h
+
+    def bvh_nodes(self):
+        return lib().orc_scene_bvh_nodes(self._h)
+
+    def bvh_depth(self):
+        return lib().orc_scene_bvh_depth(self._h)
+
+    def bvh_leaf_order(self):
+        buf = (C.c_int32 * max(self.n_prims, 1))()
+        n = lib().orc_scene_bvh_leaf_order(self._h, buf, self.n_prims)
+        return np.array(buf[:n], dtype=np.int32)
+
+    def render(self, cam, width, height, samples=1, max_depth=4, color_clamp=1.0, seed=1, mode=MODE_COLOR,
+               world_kind=WORLD_BVHNODE, threads=0, window=None, drop_remainder_rows=False, want_nodes=False):
+        p = Params(width=width, height=height, samples=samples, max_depth=max_depth, color_clamp=color_clamp, seed=seed,
+                   mode=mode, world_kind=world_kind, threads=threads, drop_remainder_rows=int(drop_remainder_rows))
+        if window is not None:
+            p.x0, p.y0, p.x1, p.y1 = window
+        out = np.zeros((height, width), dtype=np.uint32)
+        nodes = np.zeros((height, width), dtype=np.uint32) if want_nodes else None
+        st = Stats()
+        rc = lib().orc_render(self._h, C.byref(cam), C.byref(p), out.ctypes.data_as(C.c_void_p),
+                              nodes.ctypes.data_as(C.c_void_p) if want_nodes else None, C.byref(st))
+        if rc != 0:
+            raise RuntimeError("oracle: %s (rc=%d)" % (lib().orc_last_error().decode(), rc))
+        stats = {k: getattr(st, k) for k, _ in Stats._fields_}
+        if want_nodes:
+            return out, stats, nodes
+        return out, stats
+
+
+def default_scene():
+    """The literals of Game1.Initialize (Game1.cs:96-144): camera, 6 materials, 5 spheres, 2 lights."""
+    mats = [material((0.78, 0.79, 0.33), 0.0, 0.995), material((1.0, 0.65, 0.62), 1.0, 0.65), material((0.5, 0.425, 0.15), 0.0, 0.45),
+            material((0, 0, 0), 0, 0.0, (50.0, 0.5, 0.5)), material((0, 0, 0), 0, 0.0, (0.5, 0.5, 50.0)),
+            material((1.0, 0.5, 0.5), 0.0, 0.85)]
+    spheres = [Sphere(f3((2.05, 0.9, -7.25)), 3.5, 0), Sphere(f3((-4.5, 2.0, -8.0)), 2.3, 1), Sphere(f3((0, 45, -20.0)), 42.5, 2),
+               Sphere(f3((-20, 0, 0.0)), 2.0, 3), Sphere(f3((-15, 0, 6.0)), 6.0, 4)]
+    lights = [point_light((6.0, 2.0, 3.0), 5.0), point_light((0.0, 0.0, -12.0), 2.5)]
+    return Scene(mats, spheres=spheres, lights=lights)
+
+
+def default_camera(width=1280, height=720):
+    # aspectRatio = (float)width / (float)height (Game1.cs:86)
+    ratio = float(np.float32(width) / np.float32(height))
+    return camera((0, 0, 0), (-0.03, 0.875, -7.6), 63, ratio)
+
+
+def rgba_to_rgb8(img):
+    """(H, W) uint32 R|G<<8|B<<16|A<<24 -> (H, W, 3) uint8."""
+    return np.stack([(img >> s) & 0xFF for s in (0, 8, 16)], axis=-1).astype(np.uint8)

@@ -1,0 +1,1092 @@
+/*
+ * srt_oracle.cpp -- CPU restatement of helpvisa/simple_raytracer's per-pixel trace loop.
+ *
+ * TEST INFRASTRUCTURE ONLY: parity checker and CPU baseline.  The product library never
+ * includes, links or calls this file.
+ *
+ * PARITY UNPINNED: the reference is C# on MonoGame with no tests or golden vectors and no
+ * .NET toolchain is available, so this restatement was written by reading the C# and is
+ * pinned only by hand-derived known-answer tests.  MonoGame / .NET arithmetic that is not
+ * part of the reference tree (Vector3 helpers, MathHelper, Color, Math.Min/Max/Clamp,
+ * float->int casts) is restated from the published behaviour of MonoGame 3.8.0.1641 and
+ * .NET Core 3.1 (simpleRaytracer.csproj:4,29-31).
+ *
+ * It keeps the reference's structure on purpose -- heap objects, virtual dispatch, a
+ * recursive pointer-tree BVH built by the reference's own builder, per-light
+ * re-intersection, recursion for the ray tree -- because it doubles as the CPU baseline.
+ *
+ * The one deliberate change: System.Random (entropy seeded per thread, Game1.cs:44,378, so
+ * the reference is not reproducible) is replaced by a counter-based generator keyed by
+ * (seed, pixel, sample, ray-tree node, draw slot).  Next(lo,hi) keeps its integer-quantised
+ * semantics.  The GPU kernels use the same generator, which makes images comparable bit
+ * for bit.
+ *
+ * Build: g++ -O2 -std=c++17 -ffp-contract=off -fPIC -shared -pthread (see Makefile).
+ * All float arithmetic is plain IEEE binary32 in the operation order of the C#.
+ */
+#include "srt_oracle.h"
+
+#include <chrono>
+#include <cmath>
+#include <cstdint>
+#include <cstdio>
+#include <cstring>
+#include <limits>
+#include <memory>
+#include <string>
+#include <thread>
+#include <vector>
+
+namespace {
+
+thread_local std::string g_error;
+
+// ---------------------------------------------------------------------------------------
+// MonoGame Vector3 (Microsoft.Xna.Framework.Vector3, 3.8.0) -- operation order as published.
+// ---------------------------------------------------------------------------------------
+struct Vec { float X, Y, Z; };
+
+inline Vec V(float x, float y, float z) { Vec r; r.X = x; r.Y = y; r.Z = z; return r; }
+inline Vec operator+(Vec a, Vec b) { return V(a.X + b.X, a.Y + b.Y, a.Z + b.Z); }
+inline Vec operator-(Vec a, Vec b) { return V(a.X - b.X, a.Y - b.Y, a.Z - b.Z); }
+inline Vec operator-(Vec a) { return V(-a.X, -a.Y, -a.Z); }
+inline Vec operator*(Vec a, float s) { return V(a.X * s, a.Y * s, a.Z * s); }
+inline Vec operator*(float s, Vec a) { return V(a.X * s, a.Y * s, a.Z * s); }
+inline Vec operator*(Vec a, Vec b) { return V(a.X * b.X, a.Y * b.Y, a.Z * b.Z); }
+// Vector3 / float multiplies by the reciprocal.
+inline Vec operator/(Vec a, float s) { float factor = 1.0f / s; return V(a.X * factor, a.Y * factor, a.Z * factor); }
+
+// (float)Math.Sqrt(x): double sqrt of a float, rounded back -- equals correctly rounded sqrtf.
+inline float SqrtF(float v) { return (float)std::sqrt((double)v); }
+
+inline float Dot(Vec a, Vec b) { return a.X * b.X + a.Y * b.Y + a.Z * b.Z; }
+inline Vec Cross(Vec a, Vec b)
+{
+    float x = a.Y * b.Z - b.Y * a.Z;
+    float y = -(a.X * b.Z - b.X * a.Z);
+    float z = a.X * b.Y - b.X * a.Y;
+    return V(x, y, z);
+}
+inline float LengthOf(Vec a) { return SqrtF((a.X * a.X) + (a.Y * a.Y) + (a.Z * a.Z)); }
+inline Vec Normalize(Vec a)
+{
+    float factor = SqrtF((a.X * a.X) + (a.Y * a.Y) + (a.Z * a.Z));
+    factor = 1.0f / factor;
+    return V(a.X * factor, a.Y * factor, a.Z * factor);
+}
+inline float DistanceSquared(Vec a, Vec b)
+{
+    return (a.X - b.X) * (a.X - b.X) + (a.Y - b.Y) * (a.Y - b.Y) + (a.Z - b.Z) * (a.Z - b.Z);
+}
+inline float Distance(Vec a, Vec b) { return SqrtF(DistanceSquared(a, b)); }
+inline Vec Reflect(Vec v, Vec n)
+{
+    float d = ((v.X * n.X) + (v.Y * n.Y)) + (v.Z * n.Z);
+    return V(v.X - (2.0f * n.X) * d, v.Y - (2.0f * n.Y) * d, v.Z - (2.0f * n.Z) * d);
+}
+inline float LerpF(float a, float b, float t) { return a + (b - a) * t; }
+inline Vec Lerp(Vec a, Vec b, float t) { return V(LerpF(a.X, b.X, t), LerpF(a.Y, b.Y, t), LerpF(a.Z, b.Z, t)); }
+inline float BaryF(float v1, float v2, float v3, float a1, float a2) { return v1 + (v2 - v1) * a1 + (v3 - v1) * a2; }
+inline Vec Barycentric(Vec a, Vec b, Vec c, float u, float v)
+{
+    return V(BaryF(a.X, b.X, c.X, u, v), BaryF(a.Y, b.Y, c.Y, u, v), BaryF(a.Z, b.Z, c.Z, u, v));
+}
+inline float ToRadians(float deg) { return (float)(deg * 0.017453292519943295769236907684886); }
+inline float ToDegrees(float rad) { return (float)(rad * 57.295779513082320876798154814105); }
+
+// .NET Core 3.1 System.Math for float: Min/Max propagate NaN, Clamp passes NaN through.
+inline bool IsNeg(float v) { return std::signbit(v); }
+inline float MaxF(float a, float b)
+{
+    if ((a > b) || (a != a)) return a;
+    if (a == b) return IsNeg(a) ? b : a;
+    return b;
+}
+inline float MinF(float a, float b)
+{
+    if ((a < b) || (a != a)) return a;
+    if (a == b) return IsNeg(a) ? a : b;
+    return b;
+}
+inline float ClampF(float v, float lo, float hi)
+{
+    if (v < lo) return lo;
+    if (v > hi) return hi;
+    return v;
+}
+inline int ClampI(int v, int lo, int hi) { return v < lo ? lo : (v > hi ? hi : v); }
+// (int)floatValue on x64 RyuJIT (cvttss2si): truncation; NaN / out of range -> int.MinValue.
+inline int32_t FloatToInt(float v)
+{
+    if (!(v >= -2147483648.0f && v < 2147483648.0f)) return std::numeric_limits<int32_t>::min();
+    return (int32_t)v;
+}
+// new Color(float r, float g, float b): (int)(c * 255) per channel, clamped to a byte, alpha 255.
+inline uint32_t PackColor(float r, float g, float b)
+{
+    int R = ClampI(FloatToInt(r * 255), 0, 255);
+    int G = ClampI(FloatToInt(g * 255), 0, 255);
+    int B = ClampI(FloatToInt(b * 255), 0, 255);
+    return (uint32_t)R | ((uint32_t)G << 8) | ((uint32_t)B << 16) | 0xFF000000u;
+}
+
+// ---------------------------------------------------------------------------------------
+// Counter-based RNG shared with the GPU kernels (replaces System.Random).
+//   words = pcg4d(pixel, sample, node, slot + 0x9E3779B9 * seed)
+//   Next(lo,hi) = lo + floor(word * (hi-lo) / 2^32)        (System.Random.Next(lo,hi) is
+//                 (int)(Sample() * (hi-lo)) + lo with Sample() uniform in [0,1))
+// Slots inside one ray-tree node: 0 = pixel jitter (node 0 only), 1 = reflection roughness
+// vector, 2+l = shadow jitter of light l, 0x10000+i = i-th try of the unit-sphere rejection loop.
+// Node ids: primary ray = 1; child k (0 diffuse, 1 metal, 2 reflect) of node n = 4n + k + 1.
+// ---------------------------------------------------------------------------------------
+struct RngKey { uint32_t seed, pixel, sample, node; };
+
+enum : uint32_t { SLOT_JITTER = 0, SLOT_REFLECT = 1, SLOT_LIGHT0 = 2, SLOT_SPHERE0 = 0x10000u };
+const int kMaxRejectionTries = 64;  // probability of reaching it: (1 - pi/6)^64 ~ 2e-21
+
+inline void RngWords(const RngKey& k, uint32_t slot, uint32_t w[4])
+{
+    uint32_t x = k.pixel, y = k.sample, z = k.node, t = slot + 0x9E3779B9u * k.seed;
+    x = x * 1664525u + 1013904223u;
+    y = y * 1664525u + 1013904223u;
+    z = z * 1664525u + 1013904223u;
+    t = t * 1664525u + 1013904223u;
+    x += y * t; y += z * x; z += x * y; t += y * z;
+    x ^= x >> 16; y ^= y >> 16; z ^= z >> 16; t ^= t >> 16;
+    x += y * t; y += z * x; z += x * y; t += y * z;
+    w[0] = x; w[1] = y; w[2] = z; w[3] = t;
+}
+inline int RngNext(uint32_t word, int lo, int hi)
+{
+    return lo + (int)(((uint64_t)word * (uint64_t)(uint32_t)(hi - lo)) >> 32);
+}
+
+// MiscFunctions.cs:12-15  ReturnRandomVector: three Next(-100,100)/100 draws, X then Y then Z.
+inline Vec ReturnRandomVector(const RngKey& k, uint32_t slot)
+{
+    uint32_t w[4];
+    RngWords(k, slot, w);
+    return V((float)RngNext(w[0], -100, 100) / 100, (float)RngNext(w[1], -100, 100) / 100, (float)RngNext(w[2], -100, 100) / 100);
+}
+// MiscFunctions.cs:18-23
+inline Vec ReturnRandomRangedVector(const RngKey& k, uint32_t slot, float multiplier)
+{
+    float factor = 1 - ClampF(multiplier, 0, 1);
+    uint32_t w[4];
+    RngWords(k, slot, w);
+    return V(((float)RngNext(w[0], -100, 100) / 100) * factor, ((float)RngNext(w[1], -100, 100) / 100) * factor,
+             ((float)RngNext(w[2], -100, 100) / 100) * factor);
+}
+// MiscFunctions.cs:26-34 (rejection loop; bounded here, see kMaxRejectionTries)
+inline Vec ReturnRandomUnitSphereVector(const RngKey& k)
+{
+    Vec p = V(0, 0, 0);
+    for (int i = 0; i < kMaxRejectionTries; i++) {
+        p = ReturnRandomVector(k, SLOT_SPHERE0 + (uint32_t)i);
+        if (DistanceSquared(p, V(0, 0, 0)) >= 1) continue;
+        return p;
+    }
+    return p;
+}
+// MiscFunctions.cs:41-48
+inline Vec ReturnHemisphereRandomVector(const RngKey& k, Vec normal)
+{
+    Vec unitSphere = ReturnRandomUnitSphereVector(k);
+    if (Dot(unitSphere, normal) > 0) return unitSphere;
+    return -unitSphere;
+}
+// MiscFunctions.cs:53-60: 180 degrees minus the angle, atan2 in double.
+inline float AngleBetween(Vec a, Vec b)
+{
+    float dot = Dot(a, b);
+    Vec cross = Cross(a, b);
+    float angle = (float)(3.14159265358979323846 - std::atan2((double)LengthOf(cross), (double)dot));
+    return ToDegrees(angle);
+}
+// MiscFunctions.cs:68-71: despite its name, the squared length.
+inline float Magnitude(Vec a) { return (a.X * a.X + a.Y * a.Y + a.Z * a.Z); }
+
+// ---------------------------------------------------------------------------------------
+// Scene classes (RaytracingClasses.cs)
+// ---------------------------------------------------------------------------------------
+struct Counters {
+    uint64_t rays_path = 0, rays_shadow = 0, rays_redundant = 0, box_tests = 0;
+    uint64_t sphere_tests = 0, tri_tests = 0, rect_tests = 0, hit_nodes = 0;
+    void add(const Counters& o)
+    {
+        rays_path += o.rays_path; rays_shadow += o.rays_shadow; rays_redundant += o.rays_redundant;
+        box_tests += o.box_tests; sphere_tests += o.sphere_tests; tri_tests += o.tri_tests;
+        rect_tests += o.rect_tests; hit_nodes += o.hit_nodes;
+    }
+};
+thread_local Counters* t_cnt = nullptr;
+Counters g_sink;
+inline Counters& C() { return t_cnt ? *t_cnt : g_sink; }
+
+// RaytracingClasses.cs:9-29
+struct CustomRay {
+    Vec origin, direction, dirFrac;
+    CustomRay(Vec o, Vec d)
+    {
+        origin = o;
+        direction = Normalize(d);
+        dirFrac.X = 1.0f / direction.X;
+        dirFrac.Y = 1.0f / direction.Y;
+        dirFrac.Z = 1.0f / direction.Z;
+    }
+    Vec getPos(float t) const { return origin + (t * direction); }
+};
+
+// RaytracingClasses.cs:221-262
+struct Material {
+    Vec albedo; float metalness; float smoothness; Vec emission;
+};
+
+// RaytracingClasses.cs:797-810
+struct hitRecord {
+    Vec point = V(0, 0, 0), normal = V(0, 0, 0);
+    float t = 0;
+    bool frontFace = false;
+    const Material* hitMat = nullptr;
+    void setFaceNormal(const CustomRay& ray, Vec outwardNormal)
+    {
+        frontFace = Dot(ray.direction, outwardNormal) < 0;
+        normal = frontFace ? outwardNormal : -outwardNormal;
+    }
+};
+
+// RaytracingClasses.cs:694-794 (constructor argument order is (max, min); "approach 3" slab test)
+struct AABB {
+    Vec max, min;
+    AABB(Vec inMax, Vec inMin) : max(inMax), min(inMin) {}
+    bool hit(const CustomRay& ray) const
+    {
+        C().box_tests++;
+        float t1 = (min.X - ray.origin.X) * ray.dirFrac.X;
+        float t2 = (max.X - ray.origin.X) * ray.dirFrac.X;
+        float t3 = (min.Y - ray.origin.Y) * ray.dirFrac.Y;
+        float t4 = (max.Y - ray.origin.Y) * ray.dirFrac.Y;
+        float t5 = (min.Z - ray.origin.Z) * ray.dirFrac.Z;
+        float t6 = (max.Z - ray.origin.Z) * ray.dirFrac.Z;
+        // the caller's t_min / t_max are overwritten, i.e. ignored (RaytracingClasses.cs:780-781)
+        float t_min = MaxF(MaxF(MinF(t1, t2), MinF(t3, t4)), MinF(t5, t6));
+        float t_max = MinF(MinF(MaxF(t1, t2), MaxF(t3, t4)), MaxF(t5, t6));
+        if (t_max < 0) return false;
+        if (t_min > t_max) return false;
+        return true;
+    }
+};
+
+// MiscFunctions.cs:76-86
+inline AABB surroundingBox(const AABB& box0, const AABB& box1)
+{
+    Vec small_ = V(MinF(box0.min.X, box1.min.X), MinF(box0.min.Y, box1.min.Y), MinF(box0.min.Z, box1.min.Z));
+    Vec big = V(MaxF(box0.max.X, box1.max.X), MaxF(box0.max.Y, box1.max.Y), MaxF(box0.max.Z, box1.max.Z));
+    return AABB(big, small_);
+}
+
+// RaytracingClasses.cs:265-279
+struct Surface {
+    virtual ~Surface() {}
+    virtual bool hit(const CustomRay&, float, float, hitRecord&) const { return false; }
+    virtual bool boundingBox() { return false; }
+    std::unique_ptr<AABB> bounds;  // null until boundingBox() succeeds
+    int primId = -1;               // bookkeeping for tests only (not in the reference)
+};
+
+struct NullBounds {};  // stands for the NullReferenceException the reference would throw
+
+// MiscFunctions.cs:88-105: the "centroid" is min + (min - max/2)
+inline bool boxCompare(const Surface* a, const Surface* b, int axis)
+{
+    if (!a->bounds || !b->bounds) throw NullBounds();
+    Vec aCent = a->bounds->min + (a->bounds->min - a->bounds->max / 2);
+    Vec bCent = b->bounds->min + (b->bounds->min - b->bounds->max / 2);
+    switch (axis) {
+        case 0: return aCent.X < bCent.X;
+        case 1: return aCent.Y < bCent.Y;
+        case 2: return aCent.Z < bCent.Z;
+        default: return false;
+    }
+}
+
+// RaytracingClasses.cs:449-500
+struct Sphere : Surface {
+    Vec origin; float radius; const Material* material;
+    Sphere(Vec o, float r, const Material* m) : origin(o), radius(r), material(m) {}
+    bool hit(const CustomRay& ray, float t_min, float t_max, hitRecord& record) const override
+    {
+        C().sphere_tests++;
+        Vec distance = ray.origin - origin;
+        float a = DistanceSquared(ray.direction, V(0, 0, 0));
+        float half_b = Dot(distance, ray.direction);
+        float c = DistanceSquared(distance, V(0, 0, 0)) - radius * radius;
+        float discriminant = half_b * half_b - a * c;
+        if (discriminant < 0) return false;
+        float sqrtDisc = SqrtF(discriminant);
+        float root = (-half_b - sqrtDisc) / a;
+        if (root < t_min || t_max < root) {
+            root = (-half_b + sqrtDisc) / a;
+            if (root < t_min || t_max < root) return false;
+        }
+        record.t = root;
+        record.point = ray.getPos(record.t);
+        Vec outwardNormal = Normalize((record.point - origin) / radius);
+        record.setFaceNormal(ray, outwardNormal);
+        record.hitMat = material;
+        return true;
+    }
+    bool boundingBox() override
+    {
+        bounds.reset(new AABB(origin + V(radius, radius, radius), origin - V(radius, radius, radius)));
+        return true;
+    }
+};
+
+// RaytracingClasses.cs:503-544.  t is computed as written: (-k - origin.Z / direction.Z).
+struct RectAxis : Surface {
+    float x1, x2, y1, y2, k; const Material* material;
+    RectAxis(float a, float b, float c, float d, float kk, const Material* m) : x1(a), x2(b), y1(c), y2(d), k(kk), material(m) {}
+    bool hit(const CustomRay& ray, float t_min, float t_max, hitRecord& record) const override
+    {
+        C().rect_tests++;
+        float t = (-k - ray.origin.Z / ray.direction.Z);
+        if (t < t_min || t > t_max) return false;
+        float x = ray.origin.X + (t * ray.direction.X);
+        float y = ray.origin.Y + (t * ray.direction.Y);
+        if (x < x1 || x > x2 || y < y1 || y > y2) return false;
+        if (t < 0) return false;
+        record.t = t;
+        Vec outwardNormal = V(0, 0, 1);
+        record.setFaceNormal(ray, outwardNormal);
+        record.hitMat = material;
+        record.point = ray.getPos(t);
+        return true;
+    }
+    // no boundingBox override: Surface.boundingBox() returns false and bounds stays null
+};
+
+// RaytracingClasses.cs:547-680 (Moeller-Trumbore, culling by the sign of the determinant)
+struct Tri : Surface {
+    Vec vertA, vertB, vertC, vANorm, vBNorm, vCNorm, AB, AC;
+    bool flipNormal, blend; const Material* material;
+    Tri(const float* p, const float* n, const Material* m, bool inFlip, bool blendNormals)
+    {
+        vertA = V(p[0], p[1], p[2]); vertB = V(p[3], p[4], p[5]); vertC = V(p[6], p[7], p[8]);
+        vANorm = V(n[0], n[1], n[2]); vBNorm = V(n[3], n[4], n[5]); vCNorm = V(n[6], n[7], n[8]);
+        flipNormal = inFlip; blend = blendNormals; material = m;
+        AB = vertB - vertA;
+        AC = vertC - vertA;
+    }
+    bool hit(const CustomRay& ray, float t_min, float t_max, hitRecord& record) const override
+    {
+        C().tri_tests++;
+        Vec pVec = Cross(ray.direction, AC);  // a racy instance field in the reference (:599,679); local here
+        float discriminant = Dot(AB, pVec);
+        if ((double)discriminant < 1e-8 && !flipNormal) return false;
+        else if ((double)discriminant > 1e-8 && flipNormal) return false;
+        if ((double)std::fabs(discriminant) < 1e-8) return false;
+        float invDisc = 1 / discriminant;
+        Vec tVec = ray.origin - vertA;
+        float u = Dot(tVec, pVec) * invDisc;
+        if (u < 0 || u > 1) return false;
+        Vec qVec = Cross(tVec, AB);
+        float v = Dot(ray.direction, qVec) * invDisc;
+        if (v < 0 || u + v > 1) return false;
+        float t = Dot(AC, qVec) * invDisc;
+        if (t < 0) return false;
+        if (t < t_min || t > t_max) return false;
+        record.t = t;
+        if (!blend) {
+            if (!flipNormal) record.normal = Normalize(Cross(AB, AC));
+            else record.normal = -Normalize(Cross(AB, AC));
+        } else {
+            if (!flipNormal) record.normal = Normalize(Barycentric(vANorm, vBNorm, vCNorm, u, v));
+            else record.normal = -Normalize(Barycentric(vANorm, vBNorm, vCNorm, u, v));
+        }
+        record.frontFace = true;
+        record.hitMat = material;
+        record.point = ray.getPos(t);
+        return true;
+    }
+    bool boundingBox() override
+    {
+        Vec mx, mn;
+        mx.X = MaxF(MaxF(vertA.X, vertB.X), vertC.X);
+        mx.Y = MaxF(MaxF(vertA.Y, vertB.Y), vertC.Y);
+        mx.Z = MaxF(MaxF(vertA.Z, vertB.Z), vertC.Z);
+        mn.X = MinF(MinF(vertA.X, vertB.X), vertC.X);
+        mn.Y = MinF(MinF(vertA.Y, vertB.Y), vertC.Y);
+        mn.Z = MinF(MinF(vertA.Z, vertB.Z), vertC.Z);
+        bounds.reset(new AABB(mx, mn));
+        return true;
+    }
+};
+
+// RaytracingClasses.cs:282-342
+struct SurfaceList : Surface {
+    std::vector<Surface*> surfaces;      // not owning
+    std::vector<Surface*> surfaceArray;  // snapshot taken by Init()
+    void Init()
+    {
+        if (!surfaces.empty()) {
+            for (size_t i = 0; i < surfaces.size(); i++) surfaces[i]->boundingBox();
+            boundingBox();
+            surfaceArray = surfaces;
+        }
+    }
+    bool hit(const CustomRay& ray, float t_min, float t_max, hitRecord& record) const override
+    {
+        bool hitAnything = false;
+        float closestSoFar = t_max;
+        for (size_t i = 0; i < surfaceArray.size(); i++) {
+            if (surfaceArray[i]->hit(ray, t_min, closestSoFar, record)) {
+                hitAnything = true;
+                closestSoFar = record.t;
+            }
+        }
+        return hitAnything;
+    }
+    // The un-braced else (:330-335) makes the union run on every iteration, the first one
+    // against a zero box, so every list's bounds also contain the origin.
+    bool boundingBox() override
+    {
+        if (surfaces.size() < 1) return false;
+        bool firstBox = true;
+        AABB tempBounds(V(0, 0, 0), V(0, 0, 0));
+        for (size_t i = 0; i < surfaces.size(); i++) {
+            if (!surfaces[i]->boundingBox()) return false;
+            if (firstBox) bounds.reset(new AABB(*surfaces[i]->bounds));
+            else tempBounds = *bounds;
+            bounds.reset(new AABB(surroundingBox(*surfaces[i]->bounds, tempBounds)));
+            firstBox = false;
+        }
+        return true;
+    }
+};
+
+// RaytracingClasses.cs:344-446
+struct BVHNode : Surface {
+    Surface* left = nullptr;
+    Surface* right = nullptr;
+    std::vector<std::unique_ptr<Surface>> owned;  // child BVHNodes / lists created here
+    int depthBelow = 1;
+    int nodeCount = 1;
+
+    explicit BVHNode(SurfaceList& list)
+    {
+        if (!list.bounds) throw NullBounds();
+        int axis;
+        float sizeX = std::fabs(list.bounds->max.X - list.bounds->min.X);
+        float sizeY = std::fabs(list.bounds->max.Y - list.bounds->min.Y);
+        float sizeZ = std::fabs(list.bounds->max.Z - list.bounds->min.Z);
+        if (sizeX > MaxF(sizeY, sizeZ)) axis = 0;
+        else if (sizeY > MaxF(sizeX, sizeZ)) axis = 1;
+        else if (sizeZ > MaxF(sizeX, sizeY)) axis = 2;
+        else axis = 0;
+
+        if (list.surfaces.size() == 1) {
+            left = right = list.surfaces[0];
+            bounds.reset(new AABB(*list.bounds));
+        } else if (list.surfaces.size() == 2) {
+            if (boxCompare(list.surfaces[0], list.surfaces[1], axis)) {
+                left = list.surfaces[1];
+                right = list.surfaces[0];
+            } else {
+                left = list.surfaces[0];
+                right = list.surfaces[1];
+            }
+            if (!left->bounds || !right->bounds) throw NullBounds();
+            bounds.reset(new AABB(surroundingBox(*right->bounds, *left->bounds)));
+        } else {
+            auto leftList = std::make_unique<SurfaceList>();
+            auto rightList = std::make_unique<SurfaceList>();
+            // a single bubble pass, not a sort (:392-401)
+            for (size_t i = 0; i + 1 < list.surfaces.size(); i++) {
+                if (boxCompare(list.surfaces[i], list.surfaces[i + 1], axis)) {
+                    Surface* temp = list.surfaces[i];
+                    list.surfaces[i] = list.surfaces[i + 1];
+                    list.surfaces[i + 1] = temp;
+                }
+            }
+            size_t mid = list.surfaces.size() / 2;
+            for (size_t l = 0; l < mid; l++) leftList->surfaces.push_back(list.surfaces[l]);
+            for (size_t r = mid; r < list.surfaces.size(); r++) rightList->surfaces.push_back(list.surfaces[r]);
+            leftList->Init();
+            rightList->Init();
+            // Count > 2 always holds in this branch, so both children are BVHNodes (:412-416)
+            auto l = std::make_unique<BVHNode>(*leftList);
+            auto r = std::make_unique<BVHNode>(*rightList);
+            left = l.get();
+            right = r.get();
+            depthBelow = 1 + (l->depthBelow > r->depthBelow ? l->depthBelow : r->depthBelow);
+            nodeCount = 1 + l->nodeCount + r->nodeCount;
+            owned.push_back(std::move(l));
+            owned.push_back(std::move(r));
+            bounds.reset(new AABB(surroundingBox(*right->bounds, *left->bounds)));
+        }
+    }
+    bool hit(const CustomRay& ray, float t_min, float t_max, hitRecord& record) const override
+    {
+        if (!bounds->hit(ray)) return false;
+        bool hitLeft = false;
+        bool hitRight = false;
+        if ((hitLeft = left->hit(ray, t_min, t_max, record))) t_max = record.t;
+        if ((hitRight = right->hit(ray, t_min, t_max, record))) t_max = record.t;
+        return hitLeft || hitRight;
+    }
+    void leafOrder(std::vector<int>& out) const
+    {
+        const BVHNode* l = dynamic_cast<const BVHNode*>(left);
+        const BVHNode* r = dynamic_cast<const BVHNode*>(right);
+        if (l) l->leafOrder(out); else out.push_back(left->primId);
+        if (left == right) return;
+        if (r) r->leafOrder(out); else out.push_back(right->primId);
+    }
+};
+
+// RaytracingClasses.cs:67-219
+struct Light {
+    virtual ~Light() {}
+    virtual Vec calculateLight(Vec, const CustomRay&, const Surface*, hitRecord&, const RngKey&, uint32_t, bool) const { return V(0, 0, 0); }
+};
+
+struct PointLight : Light {
+    Vec position; float brightness; Vec lightColor;
+    PointLight(Vec p, float b, Vec c) : position(p), brightness(b), lightColor(c) {}
+
+    // RaytracingClasses.cs:96-188, blinnPhong == false branch (GetLights hard-codes false,
+    // RaytracingOperations.cs:202; the Blinn branch is unreachable from the trace loop).
+    Vec calculateLight(Vec formerLightLevel, const CustomRay& ray, const Surface* world, hitRecord& record,
+                       const RngKey& key, uint32_t lightIndex, bool /*blinnPhong*/) const override
+    {
+        float roughness = 1 - record.hitMat->smoothness;
+        float roughSqr = roughness * roughness;
+        float geoShadow = 1;
+        float attenuation = ClampF(1 / DistanceSquared(record.point, position), 0, 1);
+
+        Vec directionToLight = Normalize((position - record.point));
+        Vec halfAngle = Normalize(directionToLight + Normalize(-ray.direction));
+
+        float NdotL = ClampF(Dot(record.normal, directionToLight), 0, 1);
+        float NdotV = ClampF(Dot(record.normal, Normalize(-ray.direction)), 0, 1);
+        float LdotH = ClampF(Dot(directionToLight, halfAngle), 0, 1);
+        float NdotH = ClampF(Dot(record.normal, halfAngle), 0, 1);
+
+        float ggx = 0;
+        {
+            float NdotLSqr = NdotL * NdotL;
+            float NdotVSqr = NdotV * NdotV;
+            float SmithL = 2 / (1 + SqrtF(1 + roughSqr * (1 - NdotLSqr) / NdotLSqr));
+            float SmithV = 2 / (1 + SqrtF(1 + roughSqr * (1 - NdotVSqr) / NdotVSqr));
+            geoShadow = SmithL * SmithV;
+
+            float F, D, vis;
+            float aSqr = roughSqr;
+            float pi = (float)3.14159265358979323846;
+            float denom = NdotH * NdotH * (aSqr - 1.0f) + 1.0f;
+            D = aSqr / (pi * denom * denom);
+
+            float LdotH5 = (float)std::pow((double)(1.0f - LdotH), 5.0);
+            float f0 = 0.5f;
+            F = f0 + (1.0f - f0) * LdotH5;
+
+            float k = roughSqr / 2.0f;
+            vis = (1.0f / (NdotL * (1.0f - k) + k)) * (1.0f / (NdotV * (1.0f - k) + k));
+
+            ggx = NdotL * D * F * vis;
+            ggx *= (brightness / 2);
+        }
+
+        Vec lightAlbedo = (record.hitMat->albedo + lightColor);
+        Vec lightLevel = formerLightLevel
+            + ((lightAlbedo * (1 - record.hitMat->metalness)) * (NdotL * NdotV) * geoShadow * brightness * attenuation);
+
+        // Shadow ray.  It is a closest-hit query that overwrites `record`, so from here on
+        // record.point / record.t / record.hitMat belong to the occluder if there is one.
+        C().rays_shadow++;
+        if (world->hit(CustomRay(record.point, directionToLight + ReturnRandomRangedVector(key, SLOT_LIGHT0 + lightIndex, 0.95f)),
+                       0.001f, std::numeric_limits<float>::infinity(), record))
+            if (Magnitude(CustomRay(record.point, directionToLight).getPos(record.t) - record.point) < Magnitude(position - record.point)) {
+                lightLevel = formerLightLevel;
+                ggx = 0;
+            }
+
+        return lightLevel
+            + ((Lerp(V(1, 1, 1) + lightColor, lightAlbedo, record.hitMat->metalness) / (float)3.14159265358979323846) * ggx * attenuation);
+    }
+};
+
+struct LightList : Light {
+    std::vector<std::unique_ptr<PointLight>> lightArray;
+    // RaytracingClasses.cs:205-218: re-intersects the ray once per light; `+=` on a value that
+    // already contains formerLightLevel doubles it: f <- 2f + c_i.
+    Vec calculateLight(Vec formerLightLevel, const CustomRay& ray, const Surface* world, hitRecord& record,
+                       const RngKey& key, uint32_t, bool blinnPhong) const override
+    {
+        for (size_t i = 0; i < lightArray.size(); i++) {
+            C().rays_redundant++;
+            if (world->hit(ray, 0.01f, std::numeric_limits<float>::infinity(), record)) {
+                formerLightLevel = formerLightLevel + lightArray[i]->calculateLight(formerLightLevel, ray, world, record, key, (uint32_t)i, blinnPhong);
+            }
+        }
+        return formerLightLevel;
+    }
+};
+
+// ---------------------------------------------------------------------------------------
+// RayOperations (RaytracingOperations.cs)
+// ---------------------------------------------------------------------------------------
+const float kInf = std::numeric_limits<float>::infinity();
+
+// :197-205
+Vec GetLights(const CustomRay& ray, const Surface* world, const RngKey& key, const Light* light)
+{
+    hitRecord record;
+    Vec formerLightLevel = V(0, 0, 0);
+    formerLightLevel = light->calculateLight(formerLightLevel, ray, world, record, key, 0, false);
+    return formerLightLevel;
+}
+
+// :88-116 -- only the depth edits matter; the `samples` edits feed nothing (the value is
+// passed down and never read).
+int DepthHeuristic(int depth, float smoothness)
+{
+    if (smoothness < 0.6f) depth -= (int)((float)depth / 4);
+    if (smoothness < 0.4f) depth -= (int)((float)depth / 2);
+    if (smoothness < 0.2f) depth -= (int)((float)depth / 2);
+    if (smoothness <= 0.05f) depth = 1;
+    return ClampI(depth, 1, 999999);
+}
+
+Vec Sky(Vec direction)
+{
+    float t = 0.5f * (direction.Y + 1);
+    return t * V(0.2f, 0.17f, 0.17f) + (1 - t) * V(0.25f, 0.22f, 0.23f);
+}
+
+// :75-195
+Vec GetRayColor(const CustomRay& ray, const Surface* world, RngKey key, int depth, const Light* light, float clamp,
+                uint32_t* nodeCounter)
+{
+    hitRecord record;
+    Vec direction = ray.direction;
+
+    if (depth < 1) return V(0, 0, 0);
+
+    C().rays_path++;
+    if (nodeCounter) (*nodeCounter)++;
+    if (world->hit(ray, 0.01f, kInf, record)) {
+        C().hit_nodes++;
+        const Material& m = *record.hitMat;
+        depth = DepthHeuristic(depth, m.smoothness);
+
+        Vec diffuseDirection = record.normal + ReturnHemisphereRandomVector(key, record.normal);
+        Vec reflectedDirection = Reflect(direction, record.normal + ReturnRandomRangedVector(key, SLOT_REFLECT, SqrtF(m.smoothness)));
+
+        float fresnel = (AngleBetween(direction, reflectedDirection) / 180);
+        fresnel *= fresnel;
+
+        Vec finalColor = V(0, 0, 0);
+        Vec lightColor = GetLights(ray, world, key, light);
+        bool doMetalPass = true;
+        bool doReflectPass = true;
+        if (m.metalness == 0) doMetalPass = false;
+        if (m.metalness == 1) doReflectPass = false;
+
+        RngKey kd = key, km = key, kr = key;
+        kd.node = key.node * 4u + 1u;
+        km.node = key.node * 4u + 2u;
+        kr.node = key.node * 4u + 3u;
+
+        if (doMetalPass && doReflectPass) {
+            finalColor = (m.emission + (m.albedo * (1 - m.metalness))
+                          * 0.7f * (GetRayColor(CustomRay(record.point, diffuseDirection), world, kd, depth - 1, light, clamp, nodeCounter)))
+                + (m.albedo * m.metalness)
+                * GetRayColor(CustomRay(record.point, reflectedDirection), world, km, depth - 1, light, clamp, nodeCounter)
+                + (1 - m.metalness) * (fresnel * (m.smoothness * m.smoothness))
+                * GetRayColor(CustomRay(record.point, reflectedDirection), world, kr, depth - 1, light, clamp, nodeCounter)
+                + lightColor;
+        } else if (doMetalPass && !doReflectPass) {
+            finalColor = (m.emission + (m.albedo * (1 - m.metalness))
+                          * 0.7f * (GetRayColor(CustomRay(record.point, diffuseDirection), world, kd, depth - 1, light, clamp, nodeCounter)))
+                + (m.albedo * m.metalness)
+                * GetRayColor(CustomRay(record.point, reflectedDirection), world, km, depth - 1, light, clamp, nodeCounter)
+                + lightColor;
+        } else if (!doMetalPass && doReflectPass) {
+            finalColor = (m.emission + (m.albedo * (1 - m.metalness))
+                          * 0.7f * (GetRayColor(CustomRay(record.point, diffuseDirection), world, kd, depth - 1, light, clamp, nodeCounter)))
+                + (1 - m.metalness) * (fresnel * (m.smoothness * m.smoothness))
+                * GetRayColor(CustomRay(record.point, reflectedDirection), world, kr, depth - 1, light, clamp, nodeCounter)
+                + lightColor;
+        }
+
+        finalColor.X = ClampF(finalColor.X, 0, clamp);
+        finalColor.Y = ClampF(finalColor.Y, 0, clamp);
+        finalColor.Z = ClampF(finalColor.Z, 0, clamp);
+        return finalColor;
+    }
+    return Sky(direction);
+}
+
+// :11-21
+Vec GetRayNormalColor(const CustomRay& ray, const Surface* world)
+{
+    hitRecord record;
+    if (world->hit(ray, 0, kInf, record)) return 0.5f * (record.normal + V(1, 1, 1));
+    Vec direction = Normalize(ray.direction);
+    float t = 0.5f * (direction.Y + 1);
+    return t * V(0.2f, 0.2f, 0.2f) + (1 - t) * V(0.5f, 0.7f, 1);
+}
+
+// :24-35
+Vec GetRayDepthColor(const CustomRay& ray, const Surface* world)
+{
+    hitRecord record;
+    if (world->hit(ray, 0, kInf, record)) {
+        float value = Distance(ray.origin, record.point);
+        return V(1, 1, 1) - (0.07f * V(value, value, value));
+    }
+    Vec direction = Normalize(ray.direction);
+    float t = 0.5f * (direction.Y + 1);
+    return t * V(0, 0, 0);
+}
+
+}  // namespace
+
+// ---------------------------------------------------------------------------------------
+// Scene container + render driver (Game1.cs)
+// ---------------------------------------------------------------------------------------
+struct orc_scene {
+    std::vector<Material> materials;
+    std::vector<std::unique_ptr<Surface>> prims;
+    SurfaceList world;
+    std::unique_ptr<BVHNode> nodeWorld;
+    bool bvhWouldThrow = false;
+    LightList lights;
+    bool empty = true;
+};
+
+namespace {
+
+struct EmptyWorld : Surface {};  // hit() is always false
+
+const Surface* pickWorld(const orc_scene* s, int kind)
+{
+    static EmptyWorld nothing;
+    if (s->empty) return &nothing;
+    if (kind == ORC_WORLD_SURFACELIST) return &s->world;
+    if (s->bvhWouldThrow || !s->nodeWorld) return nullptr;
+    return s->nodeWorld.get();
+}
+
+Vec A3(const float* p) { return V(p[0], p[1], p[2]); }
+
+// Game1.cs:264-317, one band of scanlines.
+void renderBlock(const orc_scene* s, const Surface* world, const orc_camera* cam, const orc_params* p, int yStart, int yEnd,
+                 int xStart, int xEnd, uint32_t* out, uint32_t* nodesPerPixel, Counters* counters)
+{
+    t_cnt = counters;
+    const Vec camPos = A3(cam->position), llc = A3(cam->lower_left), horiz = A3(cam->horizontal), vert = A3(cam->vertical);
+    const int samples = p->samples;
+    for (int y = yStart; y < yEnd; y++) {
+        for (int x = xStart; x < xEnd; x++) {
+            Vec vectorRayColor = V(0, 0, 0);
+            uint32_t nodes = 0;
+            RngKey key;
+            key.seed = p->seed;
+            key.pixel = (uint32_t)x + (uint32_t)y * (uint32_t)p->width;
+            for (int i = 0; i < samples; i++) {
+                key.sample = (uint32_t)i;
+                key.node = 0;
+                uint32_t w[4];
+                RngWords(key, SLOT_JITTER, w);
+                float u = (float)(x + (float)RngNext(w[0], -50, 50) / 100) / p->width;
+                float v = (float)(y + (float)RngNext(w[1], -50, 50) / 100) / p->height;
+                CustomRay ray(camPos, llc + u * horiz + v * vert - camPos);
+                key.node = 1;
+                Vec c;
+                switch (p->mode) {
+                    case ORC_MODE_NORMAL: c = GetRayNormalColor(ray, world); break;
+                    case ORC_MODE_DEPTH: c = GetRayDepthColor(ray, world); break;
+                    case ORC_MODE_LIGHTS: c = GetLights(ray, world, key, &s->lights); break;
+                    default: c = GetRayColor(ray, world, key, p->max_depth, &s->lights, p->color_clamp, &nodes); break;
+                }
+                vectorRayColor = vectorRayColor + c / (float)samples;
+            }
+            vectorRayColor.X = SqrtF(vectorRayColor.X);
+            vectorRayColor.Y = SqrtF(vectorRayColor.Y);
+            vectorRayColor.Z = SqrtF(vectorRayColor.Z);
+            // PixelOperations.WritePixel (PixelManagement.cs:8-23): re-clamps bytes, stores at x + y*width
+            out[x + (y * p->width)] = PackColor(vectorRayColor.X, vectorRayColor.Y, vectorRayColor.Z);
+            if (nodesPerPixel) nodesPerPixel[x + (y * p->width)] = nodes;
+        }
+    }
+    t_cnt = nullptr;
+}
+
+}  // namespace
+
+extern "C" {
+
+const char* orc_last_error(void) { return g_error.c_str(); }
+
+orc_scene* orc_scene_create(const orc_material* mats, int32_t n_mats, const orc_tri* tris, int32_t n_tris,
+                            const orc_sphere* spheres, int32_t n_spheres, const orc_rect* rects, int32_t n_rects,
+                            const orc_light* lights, int32_t n_lights)
+{
+    auto s = std::make_unique<orc_scene>();
+    s->materials.resize(n_mats > 0 ? n_mats : 0);
+    for (int i = 0; i < n_mats; i++) {
+        s->materials[i].albedo = A3(mats[i].albedo);
+        s->materials[i].metalness = mats[i].metalness;
+        s->materials[i].smoothness = mats[i].smoothness;
+        s->materials[i].emission = A3(mats[i].emission);
+    }
+    auto matOf = [&](int idx) -> const Material* {
+        if (idx < 0 || idx >= n_mats) return nullptr;
+        return &s->materials[idx];
+    };
+    int id = 0;
+    for (int i = 0; i < n_tris; i++) {
+        const Material* m = matOf(tris[i].material);
+        if (!m) { g_error = "triangle material index out of range"; return nullptr; }
+        auto t = std::make_unique<Tri>(tris[i].pos, tris[i].nrm, m, tris[i].flip != 0, tris[i].blend != 0);
+        t->primId = id++;
+        s->world.surfaces.push_back(t.get());
+        s->prims.push_back(std::move(t));
+    }
+    for (int i = 0; i < n_spheres; i++) {
+        const Material* m = matOf(spheres[i].material);
+        if (!m) { g_error = "sphere material index out of range"; return nullptr; }
+        auto sp = std::make_unique<Sphere>(A3(spheres[i].origin), spheres[i].radius, m);
+        sp->primId = id++;
+        s->world.surfaces.push_back(sp.get());
+        s->prims.push_back(std::move(sp));
+    }
+    for (int i = 0; i < n_rects; i++) {
+        const Material* m = matOf(rects[i].material);
+        if (!m) { g_error = "rect material index out of range"; return nullptr; }
+        auto r = std::make_unique<RectAxis>(rects[i].x1, rects[i].x2, rects[i].y1, rects[i].y2, rects[i].k, m);
+        r->primId = id++;
+        s->world.surfaces.push_back(r.get());
+        s->prims.push_back(std::move(r));
+    }
+    for (int i = 0; i < n_lights; i++)
+        s->lights.lightArray.push_back(std::make_unique<PointLight>(A3(lights[i].position), lights[i].brightness, A3(lights[i].color)));
+
+    s->empty = s->world.surfaces.empty();
+    if (!s->empty) {
+        // Game1.cs:136-137.  Init() snapshots the insertion order before the BVH builder's
+        // bubble passes permute world.surfaces.
+        s->world.Init();
+        try {
+            SurfaceList builderView;
+            builderView.surfaces = s->world.surfaces;
+            if (s->world.bounds) builderView.bounds.reset(new AABB(*s->world.bounds));
+            s->nodeWorld.reset(new BVHNode(builderView));
+        } catch (const NullBounds&) {
+            s->bvhWouldThrow = true;  // a RectAxis has no bounds: NullReferenceException in the reference
+            s->nodeWorld.reset();
+        }
+    }
+    return s.release();
+}
+
+void orc_scene_destroy(orc_scene* s) { delete s; }
+
+int32_t orc_scene_bvh_nodes(const orc_scene* s) { return s && s->nodeWorld ? s->nodeWorld->nodeCount : 0; }
+int32_t orc_scene_bvh_depth(const orc_scene* s) { return s && s->nodeWorld ? s->nodeWorld->depthBelow : 0; }
+int32_t orc_scene_bvh_leaf_order(const orc_scene* s, int32_t* out, int32_t cap)
+{
+    if (!s || !s->nodeWorld) return 0;
+    std::vector<int> order;
+    s->nodeWorld->leafOrder(order);
+    int n = (int)order.size() < cap ? (int)order.size() : cap;
+    for (int i = 0; i < n; i++) out[i] = order[i];
+    return n;
+}
+
+int orc_render(const orc_scene* s, const orc_camera* cam, const orc_params* p, uint32_t* out, uint32_t* nodesPerPixel,
+               orc_stats* stats)
+{
+    if (!s || !cam || !p || !out) { g_error = "null argument"; return -1; }
+    if (p->width <= 0 || p->height <= 0 || p->samples <= 0) { g_error = "width, height and samples must be positive"; return -1; }
+    if (!(p->color_clamp >= 0)) { g_error = "Math.Clamp(x, 0, clamp) throws when clamp < 0"; return -2; }
+    const Surface* world = pickWorld(s, p->world_kind);
+    if (!world) { g_error = "new BVHNode(world) dereferences null bounds when the world holds a RectAxis"; return -2; }
+
+    int x0 = p->x0, y0 = p->y0, x1 = p->x1, y1 = p->y1;
+    if (x0 == 0 && y0 == 0 && x1 == 0 && y1 == 0) { x1 = p->width; y1 = p->height; }
+    if (x0 < 0 || y0 < 0 || x1 > p->width || y1 > p->height || x0 > x1 || y0 > y1) { g_error = "bad window"; return -1; }
+
+    int n = p->threads > 0 ? p->threads : (int)std::thread::hardware_concurrency();
+    if (n < 1) n = 1;
+    const int rows = y1 - y0;
+    std::vector<Counters> counters(n);
+    std::vector<std::thread> pool;
+    auto t0 = std::chrono::steady_clock::now();
+    // Game1.cs:376-380: thread i renders rows [(H/N)*i, (H/N)*(i+1)).  The reference leaves the
+    // last H mod N rows unrendered; unless asked to reproduce that, the last band takes them.
+    const int band = rows / n;
+    for (int i = 0; i < n; i++) {
+        int ys = y0 + band * i;
+        int ye = y0 + band * (i + 1);
+        if (i == n - 1 && !p->drop_remainder_rows) ye = y1;
+        if (ye <= ys) continue;
+        pool.emplace_back(renderBlock, s, world, cam, p, ys, ye, x0, x1, out, nodesPerPixel, &counters[i]);
+    }
+    for (auto& t : pool) t.join();
+    auto t1 = std::chrono::steady_clock::now();
+    if (p->drop_remainder_rows) {
+        for (int y = y0 + band * n; y < y1; y++)
+            for (int x = x0; x < x1; x++) out[x + y * p->width] = 0;  // default(Color)
+    }
+    if (stats) {
+        Counters total;
+        for (auto& c : counters) total.add(c);
+        stats->rays_path = total.rays_path; stats->rays_shadow = total.rays_shadow; stats->rays_redundant = total.rays_redundant;
+        stats->box_tests = total.box_tests; stats->sphere_tests = total.sphere_tests; stats->tri_tests = total.tri_tests;
+        stats->rect_tests = total.rect_tests; stats->hit_nodes = total.hit_nodes;
+        stats->seconds = std::chrono::duration<double>(t1 - t0).count();
+        stats->threads_used = n;
+    }
+    return 0;
+}
+
+// RaytracingClasses.cs:34-50
+void orc_camera_ctor(const float origin[3], const float look_at[3], float fov_deg, float ratio, orc_camera* out)
+{
+    Vec position = A3(origin), lookAt = A3(look_at);
+    float theta = ToRadians(fov_deg);
+    float h = (float)std::tan((double)(theta / 2));
+    float viewportHeight = 2.0f * h;
+    float viewportWidth = viewportHeight * ratio;
+    Vec w = Normalize(position - lookAt);
+    Vec u = Normalize(Cross(V(0, 1, 0), w));
+    Vec v = Cross(w, u);
+    Vec horizontal = viewportWidth * u;
+    Vec vertical = viewportHeight * v;
+    Vec lowerLeftCorner = position - horizontal / 2 - vertical / 2 - w;
+    auto put = [](float* d, Vec a) { d[0] = a.X; d[1] = a.Y; d[2] = a.Z; };
+    put(out->position, position); put(out->lower_left, lowerLeftCorner); put(out->horizontal, horizontal); put(out->vertical, vertical);
+}
+
+// RaytracingClasses.cs:223-255
+void orc_material_ctor(const float albedo[3], float metal, float smooth, const float emission[3], orc_material* out)
+{
+    out->albedo[0] = ClampF(albedo[0], 0, 1);
+    out->albedo[1] = ClampF(albedo[1], 0, 1);
+    out->albedo[2] = ClampF(albedo[2], 0, 1);
+    out->metalness = ClampF(metal, 0, 1);
+    out->smoothness = ClampF(smooth, 0, 1);
+    out->emission[0] = emission[0]; out->emission[1] = emission[1]; out->emission[2] = emission[2];
+}
+
+// RaytracingClasses.cs:77-94
+void orc_pointlight_ctor(const float origin[3], float brightness, const float* color, orc_light* out)
+{
+    out->position[0] = origin[0]; out->position[1] = origin[1]; out->position[2] = origin[2];
+    out->brightness = brightness;
+    out->color[0] = out->color[1] = out->color[2] = 0;
+    if (color) {
+        out->color[0] = color[0]; out->color[1] = color[1]; out->color[2] = color[2];
+        float biggestColor1 = MaxF(color[0], color[1]);
+        float biggestColor2 = MaxF(color[1], color[2]);
+        float biggestColor3 = MaxF(biggestColor1, biggestColor2);
+        if (biggestColor3 != 0 && biggestColor3 >= 1) out->brightness /= biggestColor3;
+    }
+}
+
+static void putRec(const hitRecord& r, const std::vector<Material>* mats, float rec[9], int matIndex)
+{
+    rec[0] = r.t; rec[1] = r.point.X; rec[2] = r.point.Y; rec[3] = r.point.Z;
+    rec[4] = r.normal.X; rec[5] = r.normal.Y; rec[6] = r.normal.Z; rec[7] = r.frontFace ? 1.0f : 0.0f; rec[8] = (float)matIndex;
+    (void)mats;
+}
+
+int orc_sphere_hit(const orc_sphere* sp, const float o[3], const float d[3], float t_min, float t_max, float rec[9])
+{
+    Material m{};
+    Sphere s(A3(sp->origin), sp->radius, &m);
+    hitRecord r;
+    bool h = s.hit(CustomRay(A3(o), A3(d)), t_min, t_max, r);
+    if (h) putRec(r, nullptr, rec, sp->material);
+    return h ? 1 : 0;
+}
+int orc_rect_hit(const orc_rect* rc, const float o[3], const float d[3], float t_min, float t_max, float rec[9])
+{
+    Material m{};
+    RectAxis s(rc->x1, rc->x2, rc->y1, rc->y2, rc->k, &m);
+    hitRecord r;
+    bool h = s.hit(CustomRay(A3(o), A3(d)), t_min, t_max, r);
+    if (h) putRec(r, nullptr, rec, rc->material);
+    return h ? 1 : 0;
+}
+int orc_tri_hit(const orc_tri* tr, const float o[3], const float d[3], float t_min, float t_max, float rec[9])
+{
+    Material m{};
+    Tri s(tr->pos, tr->nrm, &m, tr->flip != 0, tr->blend != 0);
+    hitRecord r;
+    bool h = s.hit(CustomRay(A3(o), A3(d)), t_min, t_max, r);
+    if (h) putRec(r, nullptr, rec, tr->material);
+    return h ? 1 : 0;
+}
+int orc_aabb_hit(const float bmin[3], const float bmax[3], const float o[3], const float d[3])
+{
+    AABB b(A3(bmax), A3(bmin));
+    return b.hit(CustomRay(A3(o), A3(d))) ? 1 : 0;
+}
+void orc_sky(const float d[3], float rgb[3])
+{
+    Vec c = Sky(A3(d));
+    rgb[0] = c.X; rgb[1] = c.Y; rgb[2] = c.Z;
+}
+int orc_depth_heuristic(int depth, float smoothness) { return DepthHeuristic(depth, smoothness); }
+uint32_t orc_pack_color(float r, float g, float b) { return PackColor(r, g, b); }
+void orc_rng_words(uint32_t seed, uint32_t pixel, uint32_t sample, uint32_t node, uint32_t slot, uint32_t out[4])
+{
+    RngKey k{seed, pixel, sample, node};
+    RngWords(k, slot, out);
+}
+int orc_rng_next(uint32_t word, int lo, int hi) { return RngNext(word, lo, hi); }
+void orc_random_vector(uint32_t seed, uint32_t pixel, uint32_t sample, uint32_t node, uint32_t slot, float out[3])
+{
+    RngKey k{seed, pixel, sample, node};
+    Vec v = ReturnRandomVector(k, slot);
+    out[0] = v.X; out[1] = v.Y; out[2] = v.Z;
+}
+void orc_hemisphere_vector(uint32_t seed, uint32_t pixel, uint32_t sample, uint32_t node, const float n[3], float out[3])
+{
+    RngKey k{seed, pixel, sample, node};
+    Vec v = ReturnHemisphereRandomVector(k, A3(n));
+    out[0] = v.X; out[1] = v.Y; out[2] = v.Z;
+}
+float orc_angle_between(const float a[3], const float b[3]) { return AngleBetween(A3(a), A3(b)); }
+
+int orc_get_lights(const orc_scene* s, int world_kind, const float o[3], const float d[3], uint32_t seed, uint32_t pixel,
+                   uint32_t sample, uint32_t node, float rgb[3])
+{
+    const Surface* world = pickWorld(s, world_kind);
+    if (!world) return -2;
+    CustomRay ray(A3(o), A3(d));
+    hitRecord probe;
+    int hit = world->hit(ray, 0.01f, kInf, probe) ? 1 : 0;
+    RngKey k{seed, pixel, sample, node};
+    Vec c = GetLights(ray, world, k, &s->lights);
+    rgb[0] = c.X; rgb[1] = c.Y; rgb[2] = c.Z;
+    return hit;
+}
+
+void orc_get_ray_color(const orc_scene* s, int world_kind, const float o[3], const float d[3], int depth, float clamp,
+                       uint32_t seed, uint32_t pixel, uint32_t sample, float rgb[3])
+{
+    const Surface* world = pickWorld(s, world_kind);
+    rgb[0] = rgb[1] = rgb[2] = 0;
+    if (!world) return;
+    RngKey k{seed, pixel, sample, 1};
+    Vec c = GetRayColor(CustomRay(A3(o), A3(d)), world, k, depth, &s->lights, clamp, nullptr);
+    rgb[0] = c.X; rgb[1] = c.Y; rgb[2] = c.Z;
+}
+
+}  // extern "C"

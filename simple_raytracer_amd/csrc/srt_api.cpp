@@ -1,0 +1,372 @@
+// srt_api.cpp -- the C ABI of libsrt.so (include/srt.h) over the gfx950 kernels.
+//
+// There is no CPU path here: every render goes through launch_trace() on a gfx950 device, and
+// srt_create fails when there is none.
+#include <hip/hip_runtime_api.h>
+
+#include <chrono>
+#include <cstring>
+#include <string>
+
+#include "../../include/srt.h"
+#include "srt_launch.h"
+#include "srt_scene.h"
+
+using namespace srt;
+
+struct srt_ctx {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    hipEvent_t ev_begin = nullptr, ev_end = nullptr;
+    HostScene host;
+    FlatScene flat;
+    bool committed = false;
+    int world_kind = SRT_WORLD_BVHNODE;
+    Camera cam{};
+    bool has_camera = false;
+    q4 *d_nodes = nullptr, *d_prims = nullptr, *d_normals = nullptr, *d_materials = nullptr, *d_lights = nullptr;
+    uint32_t* d_out = nullptr;
+    size_t out_capacity = 0;  // pixels
+    unsigned long long* d_stats = nullptr;
+    bool stats_pending = false;
+    bool counted_pending = false;
+    srt_stats stats{};
+    // asynchronous render (srt_render_async / srt_poll / srt_wait)
+    uint32_t* h_pinned = nullptr;
+    size_t pinned_capacity = 0;
+    uint32_t* async_dst = nullptr;
+    size_t async_pixels = 0;
+    bool async_pending = false;
+    std::string error;
+};
+
+namespace {
+
+thread_local std::string g_create_error;
+
+int fail(srt_ctx* c, int code, const std::string& msg)
+{
+    if (c) c->error = msg;
+    else g_create_error = msg;
+    return code;
+}
+
+int hip_fail(srt_ctx* c, hipError_t e, const char* what)
+{
+    return fail(c, SRT_E_HIP, std::string(what) + ": " + hipGetErrorString(e));
+}
+
+#define SRT_HIP(c, call)                                         \
+    do {                                                         \
+        hipError_t e_ = (call);                                  \
+        if (e_ != hipSuccess) return hip_fail((c), e_, #call);   \
+    } while (0)
+
+void free_scene_buffers(srt_ctx* c)
+{
+    hipFree(c->d_nodes); hipFree(c->d_prims); hipFree(c->d_normals); hipFree(c->d_materials); hipFree(c->d_lights);
+    c->d_nodes = c->d_prims = c->d_normals = c->d_materials = c->d_lights = nullptr;
+}
+
+int upload(srt_ctx* c, const std::vector<q4>& src, q4** dst)
+{
+    SRT_HIP(c, hipMalloc((void**)dst, src.size() * sizeof(q4)));
+    SRT_HIP(c, hipMemcpy(*dst, src.data(), src.size() * sizeof(q4), hipMemcpyHostToDevice));
+    return SRT_OK;
+}
+
+SceneView scene_view(const srt_ctx* c)
+{
+    SceneView v;
+    v.nodes = c->d_nodes; v.prims = c->d_prims; v.normals = c->d_normals; v.materials = c->d_materials; v.lights = c->d_lights;
+    v.n_lights = c->flat.n_lights; v.list_first = c->flat.list_first; v.list_count = c->flat.list_count; v.has_bvh = c->flat.has_bvh;
+    return v;
+}
+
+// Fetches (and zeroes) the counters accumulated by the launches since the last collection, once
+// the most recent launch has finished.  kernel_ms is the duration of that most recent launch.
+int collect_stats(srt_ctx* c)
+{
+    if (!c->stats_pending) return SRT_OK;
+    SRT_HIP(c, hipEventSynchronize(c->ev_end));
+    unsigned long long s[8];
+    SRT_HIP(c, hipMemcpy(s, c->d_stats, sizeof(s), hipMemcpyDeviceToHost));
+    SRT_HIP(c, hipMemsetAsync(c->d_stats, 0, sizeof(s), c->stream));
+    SRT_HIP(c, hipStreamSynchronize(c->stream));
+    float ms = 0.0f;
+    SRT_HIP(c, hipEventElapsedTime(&ms, c->ev_begin, c->ev_end));
+    c->stats.rays_path = s[0]; c->stats.rays_shadow = s[1]; c->stats.hit_nodes = s[2];
+    c->stats.box_tests = s[3]; c->stats.sphere_tests = s[4]; c->stats.tri_tests = s[5]; c->stats.rect_tests = s[6];
+    c->stats.kernel_ms = ms;
+    c->stats_pending = false;
+    return SRT_OK;
+}
+
+int launch(srt_ctx* c, const srt_render_params* p, uint32_t* d_out, size_t capacity, hipStream_t stream, bool counted)
+{
+    if (!c->committed) return fail(c, SRT_E_STATE, "srt_commit_scene has not been called");
+    if (!c->has_camera) return fail(c, SRT_E_STATE, "srt_set_camera has not been called");
+    RenderArgs ra;
+    int rc = make_render_args(p, c->cam, ra, c->error);
+    if (rc != SRT_OK) return rc;
+    int64_t need = output_pixels(p);
+    if (need < 0) return fail(c, (int)need, "bad parameters");
+    if ((size_t)need > capacity) return fail(c, SRT_E_INVALID, "output buffer too small for this layout");
+    if (!d_out) return fail(c, SRT_E_INVALID, "output pointer is NULL");
+    SRT_HIP(c, hipSetDevice(c->device));
+    SRT_HIP(c, hipEventRecord(c->ev_begin, stream));
+    hipError_t e = launch_trace(scene_view(c), ra, c->world_kind == SRT_WORLD_BVHNODE, counted, d_out, c->d_stats, stream);
+    if (e != hipSuccess) return hip_fail(c, e, "trace kernel launch");
+    SRT_HIP(c, hipEventRecord(c->ev_end, stream));
+    c->stats_pending = true;
+    return SRT_OK;
+}
+
+int ensure_out(srt_ctx* c, size_t pixels)
+{
+    if (pixels <= c->out_capacity) return SRT_OK;
+    if (c->d_out) hipFree(c->d_out);
+    c->d_out = nullptr; c->out_capacity = 0;
+    SRT_HIP(c, hipMalloc((void**)&c->d_out, pixels * sizeof(uint32_t)));
+    c->out_capacity = pixels;
+    return SRT_OK;
+}
+
+int render_blocking(srt_ctx* c, const srt_render_params* p, uint32_t* rgba_out, bool counted)
+{
+    if (!c) return SRT_E_INVALID;
+    if (!rgba_out) return fail(c, SRT_E_INVALID, "rgba_out is NULL");
+    if (c->async_pending) return fail(c, SRT_E_STATE, "an asynchronous render is in flight");
+    int64_t n = output_pixels(p);
+    if (n < 0) { RenderArgs ra; return make_render_args(p, c->cam, ra, c->error); }
+    SRT_HIP(c, hipSetDevice(c->device));
+    int rc = ensure_out(c, (size_t)n);
+    if (rc != SRT_OK) return rc;
+    rc = collect_stats(c);  // a blocking render reports its own counters only
+    if (rc != SRT_OK) return rc;
+    rc = launch(c, p, c->d_out, c->out_capacity, c->stream, counted);
+    if (rc != SRT_OK) return rc;
+    SRT_HIP(c, hipMemcpyAsync(rgba_out, c->d_out, (size_t)n * sizeof(uint32_t), hipMemcpyDeviceToHost, c->stream));
+    SRT_HIP(c, hipStreamSynchronize(c->stream));
+    return collect_stats(c);
+}
+
+}  // namespace
+
+extern "C" {
+
+int srt_version(void) { return SRT_VERSION; }
+
+const char* srt_last_error(const srt_ctx* ctx) { return ctx ? ctx->error.c_str() : g_create_error.c_str(); }
+
+int srt_create(const srt_config* cfg, srt_ctx** out)
+{
+    if (!out) return fail(nullptr, SRT_E_INVALID, "out is NULL");
+    *out = nullptr;
+    int device = cfg ? cfg->device : 0;
+    int count = 0;
+    hipError_t e = hipGetDeviceCount(&count);
+    if (e != hipSuccess || count <= 0) return fail(nullptr, SRT_E_NO_DEVICE, "no HIP device is visible; this library has no CPU path");
+    if (device < 0 || device >= count) return fail(nullptr, SRT_E_INVALID, "device ordinal out of range");
+    hipDeviceProp_t prop;
+    e = hipGetDeviceProperties(&prop, device);
+    if (e != hipSuccess) return hip_fail(nullptr, e, "hipGetDeviceProperties");
+    if (std::strncmp(prop.gcnArchName, "gfx950", 6) != 0)
+        return fail(nullptr, SRT_E_NO_DEVICE, std::string("kernels are built for gfx950 only, device is ") + prop.gcnArchName);
+    srt_ctx* c = new srt_ctx();
+    c->device = device;
+    bool ok = hipSetDevice(device) == hipSuccess && hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) == hipSuccess &&
+              hipEventCreate(&c->ev_begin) == hipSuccess && hipEventCreate(&c->ev_end) == hipSuccess &&
+              hipMalloc((void**)&c->d_stats, 8 * sizeof(unsigned long long)) == hipSuccess &&
+              hipMemset(c->d_stats, 0, 8 * sizeof(unsigned long long)) == hipSuccess && hipDeviceSynchronize() == hipSuccess;
+    if (!ok) {
+        srt_destroy(c);
+        return fail(nullptr, SRT_E_HIP, "could not create stream / events / counters on the device");
+    }
+    *out = c;
+    return SRT_OK;
+}
+
+void srt_destroy(srt_ctx* c)
+{
+    if (!c) return;
+    hipSetDevice(c->device);
+    if (c->stream) hipStreamSynchronize(c->stream);
+    free_scene_buffers(c);
+    if (c->d_out) hipFree(c->d_out);
+    if (c->d_stats) hipFree(c->d_stats);
+    if (c->h_pinned) hipHostFree(c->h_pinned);
+    if (c->ev_begin) hipEventDestroy(c->ev_begin);
+    if (c->ev_end) hipEventDestroy(c->ev_end);
+    if (c->stream) hipStreamDestroy(c->stream);
+    delete c;
+}
+
+int srt_set_camera(srt_ctx* c, const float position[3], const float lower_left[3], const float horizontal[3], const float vertical[3])
+{
+    if (!c) return SRT_E_INVALID;
+    if (!position || !lower_left || !horizontal || !vertical) return fail(c, SRT_E_INVALID, "camera vector is NULL");
+    c->cam.position = mk3(position[0], position[1], position[2]);
+    c->cam.lower_left = mk3(lower_left[0], lower_left[1], lower_left[2]);
+    c->cam.horizontal = mk3(horizontal[0], horizontal[1], horizontal[2]);
+    c->cam.vertical = mk3(vertical[0], vertical[1], vertical[2]);
+    c->has_camera = true;
+    return SRT_OK;
+}
+
+int srt_set_materials(srt_ctx* c, const srt_material* m, uint32_t n)
+{
+    if (!c) return SRT_E_INVALID;
+    c->committed = false;
+    return host_set_materials(c->host, m, n, c->error);
+}
+int srt_set_spheres(srt_ctx* c, const float* cx, const float* cy, const float* cz, const float* r, const uint32_t* mat, uint32_t n)
+{
+    if (!c) return SRT_E_INVALID;
+    c->committed = false;
+    return host_set_spheres(c->host, cx, cy, cz, r, mat, n, c->error);
+}
+int srt_set_rects(srt_ctx* c, const float* x1, const float* x2, const float* y1, const float* y2, const float* k, const uint32_t* mat, uint32_t n)
+{
+    if (!c) return SRT_E_INVALID;
+    c->committed = false;
+    return host_set_rects(c->host, x1, x2, y1, y2, k, mat, n, c->error);
+}
+int srt_set_triangles(srt_ctx* c, const float* pos9, const float* nrm9, const uint32_t* mat, const uint8_t* flags, uint32_t n)
+{
+    if (!c) return SRT_E_INVALID;
+    c->committed = false;
+    return host_set_triangles(c->host, pos9, nrm9, mat, flags, n, c->error);
+}
+int srt_set_lights(srt_ctx* c, const srt_point_light* l, uint32_t n)
+{
+    if (!c) return SRT_E_INVALID;
+    c->committed = false;
+    return host_set_lights(c->host, l, n, c->error);
+}
+
+int srt_commit_scene(srt_ctx* c, int world_kind)
+{
+    if (!c) return SRT_E_INVALID;
+    if (c->async_pending) return fail(c, SRT_E_STATE, "an asynchronous render is in flight");
+    auto t0 = std::chrono::steady_clock::now();
+    c->committed = false;
+    int rc = flatten_scene(c->host, world_kind, c->flat, c->error);
+    if (rc != SRT_OK) return rc;
+    SRT_HIP(c, hipSetDevice(c->device));
+    SRT_HIP(c, hipStreamSynchronize(c->stream));
+    free_scene_buffers(c);
+    if ((rc = upload(c, c->flat.nodes, &c->d_nodes)) != SRT_OK) return rc;
+    if ((rc = upload(c, c->flat.prims, &c->d_prims)) != SRT_OK) return rc;
+    if ((rc = upload(c, c->flat.normals, &c->d_normals)) != SRT_OK) return rc;
+    if ((rc = upload(c, c->flat.materials, &c->d_materials)) != SRT_OK) return rc;
+    if ((rc = upload(c, c->flat.lights, &c->d_lights)) != SRT_OK) return rc;
+    c->world_kind = world_kind;
+    c->committed = true;
+    c->stats.build_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+    c->stats.bvh_nodes = c->flat.n_nodes;
+    c->stats.bvh_depth = c->flat.bvh_depth;
+    c->stats.n_prims = c->flat.n_prims;
+    // the host copies of the big arrays are no longer needed
+    std::vector<q4>().swap(c->flat.nodes);
+    std::vector<q4>().swap(c->flat.prims);
+    std::vector<q4>().swap(c->flat.normals);
+    return SRT_OK;
+}
+
+int srt_render(srt_ctx* c, const srt_render_params* p, uint32_t* rgba_out) { return render_blocking(c, p, rgba_out, false); }
+int srt_render_counted(srt_ctx* c, const srt_render_params* p, uint32_t* rgba_out) { return render_blocking(c, p, rgba_out, true); }
+
+int srt_render_device(srt_ctx* c, const srt_render_params* p, void* d_rgba_out, size_t capacity_pixels, void* hip_stream)
+{
+    if (!c) return SRT_E_INVALID;
+    hipStream_t s = hip_stream ? (hipStream_t)hip_stream : c->stream;
+    return launch(c, p, (uint32_t*)d_rgba_out, capacity_pixels, s, false);
+}
+
+int srt_render_async(srt_ctx* c, const srt_render_params* p, uint32_t* rgba_out)
+{
+    if (!c) return SRT_E_INVALID;
+    if (!rgba_out) return fail(c, SRT_E_INVALID, "rgba_out is NULL");
+    if (c->async_pending) return fail(c, SRT_E_STATE, "an asynchronous render is already in flight");
+    int64_t n = output_pixels(p);
+    if (n < 0) { RenderArgs ra; return make_render_args(p, c->cam, ra, c->error); }
+    SRT_HIP(c, hipSetDevice(c->device));
+    int rc = ensure_out(c, (size_t)n);
+    if (rc != SRT_OK) return rc;
+    if ((size_t)n > c->pinned_capacity) {
+        if (c->h_pinned) hipHostFree(c->h_pinned);
+        c->h_pinned = nullptr; c->pinned_capacity = 0;
+        SRT_HIP(c, hipHostMalloc((void**)&c->h_pinned, (size_t)n * sizeof(uint32_t), hipHostMallocDefault));
+        c->pinned_capacity = (size_t)n;
+    }
+    rc = launch(c, p, c->d_out, c->out_capacity, c->stream, false);
+    if (rc != SRT_OK) return rc;
+    // ev_end marks the end of the kernel; the copy to pinned memory follows it on the same stream
+    SRT_HIP(c, hipMemcpyAsync(c->h_pinned, c->d_out, (size_t)n * sizeof(uint32_t), hipMemcpyDeviceToHost, c->stream));
+    c->async_dst = rgba_out;
+    c->async_pixels = (size_t)n;
+    c->async_pending = true;
+    return SRT_OK;
+}
+
+static int finish_async(srt_ctx* c)
+{
+    std::memcpy(c->async_dst, c->h_pinned, c->async_pixels * sizeof(uint32_t));
+    c->async_pending = false;
+    return collect_stats(c);
+}
+
+int srt_poll(srt_ctx* c, int* done)
+{
+    if (!c) return SRT_E_INVALID;
+    if (!done) return fail(c, SRT_E_INVALID, "done is NULL");
+    if (!c->async_pending) { *done = 1; return SRT_OK; }
+    hipError_t e = hipStreamQuery(c->stream);
+    if (e == hipErrorNotReady) { *done = 0; return SRT_OK; }
+    if (e != hipSuccess) return hip_fail(c, e, "hipStreamQuery");
+    *done = 1;
+    return finish_async(c);
+}
+
+int srt_wait(srt_ctx* c)
+{
+    if (!c) return SRT_E_INVALID;
+    if (!c->async_pending) return SRT_OK;
+    SRT_HIP(c, hipStreamSynchronize(c->stream));
+    return finish_async(c);
+}
+
+int srt_get_stats(srt_ctx* c, srt_stats* out)
+{
+    if (!c) return SRT_E_INVALID;
+    if (!out) return fail(c, SRT_E_INVALID, "out is NULL");
+    int rc = collect_stats(c);
+    if (rc != SRT_OK) return rc;
+    *out = c->stats;
+    return SRT_OK;
+}
+
+int64_t srt_local_pixels(const srt_render_params* p) { return output_pixels(p); }
+
+int srt_assemble_tiles(srt_ctx* c, const srt_render_params* p, const void* d_gathered, size_t stride_pixels, void* d_frame, void* hip_stream)
+{
+    if (!c) return SRT_E_INVALID;
+    if (!d_gathered || !d_frame) return fail(c, SRT_E_INVALID, "device pointer is NULL");
+    RenderArgs ra;
+    Camera none{};
+    srt_render_params q = *p;
+    q.rank = 0;
+    int rc = make_render_args(&q, none, ra, c->error);
+    if (rc != SRT_OK) return rc;
+    srt_render_params worst = q;
+    worst.layout = SRT_LAYOUT_TILES;
+    if ((int64_t)stride_pixels < output_pixels(&worst)) return fail(c, SRT_E_INVALID, "stride_pixels smaller than rank 0's tile buffer");
+    SRT_HIP(c, hipSetDevice(c->device));
+    hipStream_t s = hip_stream ? (hipStream_t)hip_stream : c->stream;
+    hipError_t e = launch_assemble(ra, (const uint32_t*)d_gathered, stride_pixels, (uint32_t*)d_frame, s);
+    if (e != hipSuccess) return hip_fail(c, e, "assemble kernel launch");
+    return SRT_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,797 @@
+// srt_core.h -- the per-path trace loop: ray generation, intersection, BVH traversal, shading.
+//
+// Everything here is `SRT_HD` (host + device) so that the same source runs inside the gfx950
+// kernels (srt_kernels.hip) and inside a CPU harness used by the tests to debug kernel logic
+// without a GPU.  The harness is not part of the product library.
+//
+// Arithmetic contract: every float operation that feeds a comparison, a ray or a colour is
+// written in the operation order of the reference C# (file:line cited at each function) and
+// must be compiled with floating-point contraction off and correctly rounded division and
+// square root.  Under that contract the image is a pure function of (scene, camera,
+// parameters, seed) and is reproduced bit for bit by any conforming CPU or GPU.
+#ifndef SRT_CORE_H
+#define SRT_CORE_H
+
+#include <stdint.h>
+#include <math.h>
+
+#if defined(__HIPCC__)
+#include <hip/hip_runtime.h>
+#define SRT_HD __host__ __device__ __forceinline__
+#else
+#define SRT_HD inline
+#endif
+
+namespace srt {
+
+// ------------------------------------------------------------------------------------------
+// small vector type; op order follows MonoGame's Vector3 (3.8.0) helpers
+// ------------------------------------------------------------------------------------------
+struct f3 { float x, y, z; };
+struct q4 { float x, y, z, w; };  // one 16-byte device word
+
+SRT_HD f3 mk3(float x, float y, float z) { f3 r; r.x = x; r.y = y; r.z = z; return r; }
+SRT_HD f3 add3(f3 a, f3 b) { return mk3(a.x + b.x, a.y + b.y, a.z + b.z); }
+SRT_HD f3 sub3(f3 a, f3 b) { return mk3(a.x - b.x, a.y - b.y, a.z - b.z); }
+SRT_HD f3 neg3(f3 a) { return mk3(-a.x, -a.y, -a.z); }
+SRT_HD f3 scale3(f3 a, float s) { return mk3(a.x * s, a.y * s, a.z * s); }
+SRT_HD f3 mul3(f3 a, f3 b) { return mk3(a.x * b.x, a.y * b.y, a.z * b.z); }
+
+SRT_HD float sqrt_rn(float v)
+{
+#if defined(__HIP_DEVICE_COMPILE__)
+    return __fsqrt_rn(v);
+#else
+    return sqrtf(v);
+#endif
+}
+SRT_HD float dot3(f3 a, f3 b) { return a.x * b.x + a.y * b.y + a.z * b.z; }
+SRT_HD float lensq3(f3 a) { return a.x * a.x + a.y * a.y + a.z * a.z; }
+SRT_HD f3 cross3(f3 a, f3 b)
+{
+    return mk3(a.y * b.z - b.y * a.z, -(a.x * b.z - b.x * a.z), a.x * b.y - b.x * a.y);
+}
+// Vector3.Normalize: factor = 1 / sqrt(x^2 + y^2 + z^2), then three multiplies.
+SRT_HD f3 normalize3(f3 a)
+{
+    float f = 1.0f / sqrt_rn((a.x * a.x) + (a.y * a.y) + (a.z * a.z));
+    return mk3(a.x * f, a.y * f, a.z * f);
+}
+SRT_HD float distsq3(f3 a, f3 b)
+{
+    float dx = a.x - b.x, dy = a.y - b.y, dz = a.z - b.z;
+    return dx * dx + dy * dy + dz * dz;
+}
+// Vector3.Reflect(v, n) = v - (2 n) (v . n)
+SRT_HD f3 reflect3(f3 v, f3 n)
+{
+    float d = ((v.x * n.x) + (v.y * n.y)) + (v.z * n.z);
+    return mk3(v.x - (2.0f * n.x) * d, v.y - (2.0f * n.y) * d, v.z - (2.0f * n.z) * d);
+}
+SRT_HD float clampf(float v, float lo, float hi) { return v < lo ? lo : (v > hi ? hi : v); }  // System.Math.Clamp: NaN passes
+SRT_HD uint32_t fbits(float f) { union { float f; uint32_t u; } c; c.f = f; return c.u; }
+SRT_HD float bitsf(uint32_t u) { union { float f; uint32_t u; } c; c.u = u; return c.f; }
+
+// new Color(float, float, float): (int)(c*255) truncated, clamped to a byte; NaN and values
+// beyond the int range convert to int.MinValue on x64 and therefore clamp to 0.  Alpha 255.
+SRT_HD uint32_t to_byte(float c)
+{
+    float v = c * 255.0f;
+    if (!(v >= 0.0f && v < 2147483648.0f)) return 0u;
+    int32_t i = (int32_t)v;
+    return i > 255 ? 255u : (uint32_t)i;
+}
+SRT_HD uint32_t pack_color(float r, float g, float b) { return to_byte(r) | (to_byte(g) << 8) | (to_byte(b) << 16) | 0xFF000000u; }
+
+// ------------------------------------------------------------------------------------------
+// Counter-based RNG (stands in for System.Random, which the reference seeds from entropy per
+// thread, Game1.cs:44,378).  Four words = pcg4d(pixel, sample, node, slot + 0x9E3779B9*seed);
+// Next(lo,hi) = lo + floor(word*(hi-lo) / 2^32), the integer-quantised draw of Random.Next.
+// ------------------------------------------------------------------------------------------
+enum : uint32_t { SLOT_JITTER = 0u, SLOT_REFLECT = 1u, SLOT_LIGHT0 = 2u, SLOT_SPHERE0 = 0x10000u };
+enum { MAX_REJECTION_TRIES = 64 };
+
+struct RngKey { uint32_t seed, pixel, sample, node; };
+
+SRT_HD void rng_words(const RngKey& k, uint32_t slot, uint32_t& a, uint32_t& b, uint32_t& c, uint32_t& d)
+{
+    uint32_t x = k.pixel, y = k.sample, z = k.node, t = slot + 0x9E3779B9u * k.seed;
+    x = x * 1664525u + 1013904223u;
+    y = y * 1664525u + 1013904223u;
+    z = z * 1664525u + 1013904223u;
+    t = t * 1664525u + 1013904223u;
+    x += y * t; y += z * x; z += x * y; t += y * z;
+    x ^= x >> 16; y ^= y >> 16; z ^= z >> 16; t ^= t >> 16;
+    x += y * t; y += z * x; z += x * y; t += y * z;
+    a = x; b = y; c = z; d = t;
+}
+SRT_HD int rng_next(uint32_t word, int lo, int hi)
+{
+#if defined(__HIP_DEVICE_COMPILE__)
+    return lo + (int)__umulhi(word, (uint32_t)(hi - lo));
+#else
+    return lo + (int)(((uint64_t)word * (uint64_t)(uint32_t)(hi - lo)) >> 32);
+#endif
+}
+// RandomVector.ReturnRandomVector (MiscFunctions.cs:12-15): components k/100, k in [-100, 99]
+SRT_HD f3 random_vector(const RngKey& k, uint32_t slot)
+{
+    uint32_t a, b, c, d;
+    rng_words(k, slot, a, b, c, d);
+    return mk3((float)rng_next(a, -100, 100) / 100.0f, (float)rng_next(b, -100, 100) / 100.0f, (float)rng_next(c, -100, 100) / 100.0f);
+}
+// RandomVector.ReturnRandomRangedVector (MiscFunctions.cs:18-23)
+SRT_HD f3 random_ranged_vector(const RngKey& k, uint32_t slot, float multiplier)
+{
+    float factor = 1.0f - clampf(multiplier, 0.0f, 1.0f);
+    f3 r = random_vector(k, slot);
+    return mk3(r.x * factor, r.y * factor, r.z * factor);
+}
+// RandomVector.ReturnHemisphereRandomVector over ReturnRandomUnitSphereVector (MiscFunctions.cs:26-48)
+SRT_HD f3 random_hemisphere_vector(const RngKey& k, f3 normal)
+{
+    f3 p = mk3(0.0f, 0.0f, 0.0f);
+    for (int i = 0; i < MAX_REJECTION_TRIES; i++) {
+        p = random_vector(k, SLOT_SPHERE0 + (uint32_t)i);
+        if (!(lensq3(p) >= 1.0f)) break;
+    }
+    if (dot3(p, normal) > 0.0f) return p;
+    return neg3(p);
+}
+
+// ------------------------------------------------------------------------------------------
+// Device scene: 16-byte words, one gather-friendly record per primitive / node.
+// ------------------------------------------------------------------------------------------
+enum : uint32_t { PRIM_TRI = 0u, PRIM_SPHERE = 1u, PRIM_RECT = 2u };
+enum : uint32_t { INFO_FLIP = 4u, INFO_BLEND = 8u };
+enum : uint32_t { DESC_LEAF = 0x80000000u, NO_PRIM = 0xFFFFFFFFu };
+enum { STACK_DEPTH = 32, MAX_LEAF_PRIMS = 16, FRAME_SLOTS = 16 };
+
+// Primitive record, 3 words (48 bytes):
+//   tri:    (A.x A.y A.z AB.x) (AB.y AB.z AC.x AC.y) (AC.z  info order normal_index)
+//   sphere: (c.x c.y c.z r)    (-)                   (-     info order -)
+//   rect:   (x1 x2 y1 y2)      (k - - -)             (-     info order -)
+// info = type | flip<<2 | blend<<3 | material<<8.  order = rank used to break exact ties in t
+// (the surface the reference tests later wins).
+// BVH node, 2 words (32 bytes): (min.xyz, desc) (max.xyz, -).  desc of an inner node = index
+// of its left child (right = left + 1); desc of a leaf = DESC_LEAF | (count-1)<<27 | first.
+// Triangle normals, 3 words per triangle: (nA.xyz -) (nB.xyz -) (nC.xyz -).
+// Material, 2 words: (albedo.xyz metalness) (smoothness emission.xyz).
+// Light, 2 words: (position.xyz brightness) (color.xyz -).
+struct SceneView {
+    const q4* nodes;
+    const q4* prims;
+    const q4* normals;
+    const q4* materials;
+    const q4* lights;
+    uint32_t n_lights;
+    uint32_t list_first, list_count;  // primitives scanned linearly (rects; everything in tiny scenes)
+    uint32_t has_bvh;                 // nodes[0] is the root when set
+};
+
+struct Material { f3 albedo; float metalness; float smoothness; f3 emission; };
+SRT_HD Material load_material(const SceneView& sc, uint32_t idx)
+{
+    q4 a = sc.materials[2 * idx], b = sc.materials[2 * idx + 1];
+    Material m;
+    m.albedo = mk3(a.x, a.y, a.z); m.metalness = a.w; m.smoothness = b.x; m.emission = mk3(b.y, b.z, b.w);
+    return m;
+}
+
+struct Counters { uint32_t box_tests, sphere_tests, tri_tests, rect_tests; };
+
+struct Hit { float t; uint32_t prim; float u, v; uint32_t order; };
+
+// ------------------------------------------------------------------------------------------
+// Primitive tests.  Each returns true and the candidate t (and u, v for triangles) when the
+// reference's hit() would return true for the range [t_min, t_max].
+// ------------------------------------------------------------------------------------------
+// Sphere.hit (RaytracingClasses.cs:459-487); `a` = |d|^2 is hoisted by the caller.
+SRT_HD bool test_sphere(q4 s, f3 o, f3 d, float a, float t_min, float t_max, float& t_out)
+{
+    f3 oc = mk3(o.x - s.x, o.y - s.y, o.z - s.z);
+    float half_b = dot3(oc, d);
+    float c = lensq3(oc) - s.w * s.w;
+    float disc = half_b * half_b - a * c;
+    if (disc < 0.0f) return false;
+    float sq = sqrt_rn(disc);
+    float root = (-half_b - sq) / a;
+    if (root < t_min || t_max < root) {
+        root = (-half_b + sq) / a;
+        if (root < t_min || t_max < root) return false;
+    }
+    t_out = root;
+    return true;
+}
+// RectAxis.hit (RaytracingClasses.cs:516-536); t exactly as written there: -k - o.z / d.z.
+SRT_HD bool test_rect(q4 r0, float k, f3 o, f3 d, float t_min, float t_max, float& t_out)
+{
+    float t = (-k - o.z / d.z);
+    if (t < t_min || t > t_max) return false;
+    float x = o.x + (t * d.x);
+    float y = o.y + (t * d.y);
+    if (x < r0.x || x > r0.y || y < r0.z || y > r0.w) return false;
+    if (t < 0.0f) return false;
+    t_out = t;
+    return true;
+}
+// Tri.hit (RaytracingClasses.cs:597-627).  The C# compares the float determinant with the
+// double 1e-8; 0x1.5798eep-27f is the largest float below 1e-8, so "(double)det < 1e-8" is
+// "det <= that float" and "(double)det > 1e-8" is "det > that float".
+SRT_HD bool test_tri(q4 p0, q4 p1, float acz, bool flip, f3 o, f3 d, float t_min, float t_max, float& t_out, float& u_out, float& v_out)
+{
+    const float kEps = 0x1.5798eep-27f;
+    f3 A = mk3(p0.x, p0.y, p0.z), AB = mk3(p0.w, p1.x, p1.y), AC = mk3(p1.z, p1.w, acz);
+    f3 pv = cross3(d, AC);
+    float det = dot3(AB, pv);
+    if (!flip) { if (det <= kEps) return false; }
+    else { if (det > kEps) return false; }
+    if (fabsf(det) <= kEps) return false;
+    float inv = 1.0f / det;
+    f3 tv = sub3(o, A);
+    float u = dot3(tv, pv) * inv;
+    if (u < 0.0f || u > 1.0f) return false;
+    f3 qv = cross3(tv, AB);
+    float v = dot3(d, qv) * inv;
+    if (v < 0.0f || u + v > 1.0f) return false;
+    float t = dot3(AC, qv) * inv;
+    if (t < 0.0f) return false;
+    if (t < t_min || t > t_max) return false;
+    t_out = t; u_out = u; v_out = v;
+    return true;
+}
+
+template <bool COUNT>
+SRT_HD void test_prim(const SceneView& sc, uint32_t idx, f3 o, f3 d, float a, float t_min, Hit& best, Counters& cnt)
+{
+    q4 p0 = sc.prims[3 * idx], p2 = sc.prims[3 * idx + 2];
+    uint32_t info = fbits(p2.y), order = fbits(p2.z);
+    uint32_t type = info & 3u;
+    float t = 0.0f, u = 0.0f, v = 0.0f;
+    bool h;
+    if (type == PRIM_TRI) {
+        q4 p1 = sc.prims[3 * idx + 1];
+        if (COUNT) cnt.tri_tests++;
+        h = test_tri(p0, p1, p2.x, (info & INFO_FLIP) != 0u, o, d, t_min, best.t, t, u, v);
+    } else if (type == PRIM_SPHERE) {
+        if (COUNT) cnt.sphere_tests++;
+        h = test_sphere(p0, o, d, a, t_min, best.t, t);
+    } else {
+        q4 p1 = sc.prims[3 * idx + 1];
+        if (COUNT) cnt.rect_tests++;
+        h = test_rect(p0, p1.x, o, d, t_min, best.t, t);
+    }
+    // t <= best.t here.  On an exact tie the surface the reference tests later wins
+    // (SurfaceList.hit / BVHNode.hit pass the running t_max and accept t == t_max).
+    if (h && (t < best.t || best.prim == NO_PRIM || order >= best.order)) {
+        best.t = t; best.prim = idx; best.u = u; best.v = v; best.order = order;
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// Box tests
+// ------------------------------------------------------------------------------------------
+SRT_HD float min2(float a, float b) { return fminf(a, b); }
+SRT_HD float max2(float a, float b) { return fmaxf(a, b); }
+
+// AABB.hit "approach 3" (RaytracingClasses.cs:773-789): the caller's range is ignored, and
+// because System.Math.Min/Max propagate NaN (0 * inf when the origin lies on a slab plane of
+// an axis-parallel ray) any NaN makes both rejections false, i.e. counts as a hit.
+SRT_HD bool box_hit_reference(q4 n0, q4 n1, f3 o, f3 inv)
+{
+    float t1 = (n0.x - o.x) * inv.x, t2 = (n1.x - o.x) * inv.x;
+    float t3 = (n0.y - o.y) * inv.y, t4 = (n1.y - o.y) * inv.y;
+    float t5 = (n0.z - o.z) * inv.z, t6 = (n1.z - o.z) * inv.z;
+    bool any_nan = (t1 != t1) | (t2 != t2) | (t3 != t3) | (t4 != t4) | (t5 != t5) | (t6 != t6);
+    float tmin = max2(max2(min2(t1, t2), min2(t3, t4)), min2(t5, t6));
+    float tmax = min2(min2(max2(t1, t2), max2(t3, t4)), max2(t5, t6));
+    return any_nan | !((tmax < 0.0f) | (tmin > tmax));
+}
+// Conservative slab test on padded boxes with culling against the closest hit so far.
+// fminf/fmaxf drop NaNs, which treats a NaN slab as "inside" -- the conservative reading.
+SRT_HD bool box_hit_padded(q4 n0, q4 n1, f3 o, f3 inv, float t_best, float& t_near)
+{
+    float t1 = (n0.x - o.x) * inv.x, t2 = (n1.x - o.x) * inv.x;
+    float t3 = (n0.y - o.y) * inv.y, t4 = (n1.y - o.y) * inv.y;
+    float t5 = (n0.z - o.z) * inv.z, t6 = (n1.z - o.z) * inv.z;
+    float tmin = max2(max2(min2(t1, t2), min2(t3, t4)), min2(t5, t6));
+    float tmax = min2(min2(max2(t1, t2), max2(t3, t4)), max2(t5, t6));
+    t_near = tmin;
+    return !((tmax < 0.0f) | (tmin > tmax) | (tmin > t_best));
+}
+
+// ------------------------------------------------------------------------------------------
+// Closest-hit query = Surface.hit(ray, t_min, +inf, record) on the committed world.
+//   EXACT:  BVHNode.hit order and semantics (left subtree, then right; no distance culling).
+//   !EXACT: SurfaceList.hit semantics through a padded SAH BVH, near child first.
+// STACK: per-lane stack with push/pop (LDS column on the GPU).
+// ------------------------------------------------------------------------------------------
+template <int STRIDE>
+struct LaneStack {
+    uint32_t* base;
+    int sp;
+    SRT_HD void push(uint32_t v) { base[sp * STRIDE] = v; sp++; }
+    SRT_HD uint32_t pop() { sp--; return base[sp * STRIDE]; }
+};
+
+template <bool EXACT, bool COUNT, int STRIDE>
+SRT_HD Hit closest_hit(const SceneView& sc, f3 o, f3 d, float t_min, uint32_t* stack_mem, Counters& cnt)
+{
+    Hit best;
+    best.t = INFINITY; best.prim = NO_PRIM; best.u = 0.0f; best.v = 0.0f; best.order = 0u;
+    const float a = lensq3(d);  // Sphere.hit's `a`
+
+    for (uint32_t i = 0; i < sc.list_count; i++) test_prim<COUNT>(sc, sc.list_first + i, o, d, a, t_min, best, cnt);
+
+    if (sc.has_bvh) {
+        const f3 inv = mk3(1.0f / d.x, 1.0f / d.y, 1.0f / d.z);  // CustomRay.dirFrac (RaytracingClasses.cs:16-18)
+        LaneStack<STRIDE> st;
+        st.base = stack_mem; st.sp = 0;
+        q4 r0 = sc.nodes[0], r1 = sc.nodes[1];
+        if (COUNT) cnt.box_tests++;
+        float tn;
+        bool root_hit = EXACT ? box_hit_reference(r0, r1, o, inv) : box_hit_padded(r0, r1, o, inv, best.t, tn);
+        uint32_t cur = fbits(r0.w);
+        bool live = root_hit;
+        while (live) {
+            if (cur & DESC_LEAF) {
+                uint32_t first = cur & 0x07FFFFFFu, count = ((cur >> 27) & 15u) + 1u;
+                for (uint32_t i = 0; i < count; i++) test_prim<COUNT>(sc, first + i, o, d, a, t_min, best, cnt);
+                if (st.sp == 0) break;
+                cur = st.pop();
+                continue;
+            }
+            // inner node: its two children are adjacent
+            q4 l0 = sc.nodes[2 * cur], l1 = sc.nodes[2 * cur + 1];
+            q4 h0 = sc.nodes[2 * cur + 2], h1 = sc.nodes[2 * cur + 3];
+            if (COUNT) cnt.box_tests += 2;
+            uint32_t dl = fbits(l0.w), dr = fbits(h0.w);
+            bool hl, hr;
+            if (EXACT) {
+                hl = box_hit_reference(l0, l1, o, inv);
+                hr = box_hit_reference(h0, h1, o, inv);
+                if (hl) { if (hr) st.push(dr); cur = dl; }
+                else if (hr) cur = dr;
+                else { if (st.sp == 0) break; cur = st.pop(); }
+            } else {
+                float tl, tr;
+                hl = box_hit_padded(l0, l1, o, inv, best.t, tl);
+                hr = box_hit_padded(h0, h1, o, inv, best.t, tr);
+                if (hl & hr) {
+                    bool left_first = !(tr < tl);
+                    st.push(left_first ? dr : dl);
+                    cur = left_first ? dl : dr;
+                } else if (hl) cur = dl;
+                else if (hr) cur = dr;
+                else { if (st.sp == 0) break; cur = st.pop(); }
+            }
+        }
+    }
+    return best;
+}
+
+// ------------------------------------------------------------------------------------------
+// hitRecord reconstruction for the winning primitive
+// ------------------------------------------------------------------------------------------
+struct HitRecord { f3 point, normal; uint32_t material; };
+
+SRT_HD f3 ray_at(f3 o, f3 d, float t) { return mk3(o.x + (t * d.x), o.y + (t * d.y), o.z + (t * d.z)); }  // CustomRay.getPos
+
+SRT_HD uint32_t hit_material(const SceneView& sc, const Hit& h) { return fbits(sc.prims[3 * h.prim + 2].y) >> 8; }
+
+SRT_HD HitRecord resolve_hit(const SceneView& sc, const Hit& h, f3 o, f3 d)
+{
+    HitRecord r;
+    q4 p2 = sc.prims[3 * h.prim + 2];
+    uint32_t info = fbits(p2.y);
+    uint32_t type = info & 3u;
+    r.material = info >> 8;
+    r.point = ray_at(o, d, h.t);
+    if (type == PRIM_SPHERE) {
+        // RaytracingClasses.cs:482-483: Normalize((point - origin) / radius), flipped to face the ray
+        q4 s = sc.prims[3 * h.prim];
+        float f = 1.0f / s.w;
+        f3 n = normalize3(mk3((r.point.x - s.x) * f, (r.point.y - s.y) * f, (r.point.z - s.z) * f));
+        bool front = dot3(d, n) < 0.0f;
+        r.normal = front ? n : neg3(n);
+    } else if (type == PRIM_TRI) {
+        // RaytracingClasses.cs:629-643: never flipped towards the ray; frontFace is always true
+        f3 n;
+        if (info & INFO_BLEND) {
+            uint32_t ni = fbits(p2.w);
+            q4 a = sc.normals[3 * ni], b = sc.normals[3 * ni + 1], c = sc.normals[3 * ni + 2];
+            // Vector3.Barycentric: a + (b - a) u + (c - a) v per component
+            n = mk3(a.x + (b.x - a.x) * h.u + (c.x - a.x) * h.v, a.y + (b.y - a.y) * h.u + (c.y - a.y) * h.v,
+                    a.z + (b.z - a.z) * h.u + (c.z - a.z) * h.v);
+        } else {
+            q4 p0 = sc.prims[3 * h.prim], p1 = sc.prims[3 * h.prim + 1];
+            n = cross3(mk3(p0.w, p1.x, p1.y), mk3(p1.z, p1.w, p2.x));
+        }
+        n = normalize3(n);
+        r.normal = (info & INFO_FLIP) ? neg3(n) : n;
+    } else {
+        // RaytracingClasses.cs:531-532: outward normal (0,0,1), flipped to face the ray
+        bool front = dot3(d, mk3(0.0f, 0.0f, 1.0f)) < 0.0f;
+        r.normal = front ? mk3(0.0f, 0.0f, 1.0f) : mk3(-0.0f, -0.0f, -1.0f);
+    }
+    return r;
+}
+
+// ------------------------------------------------------------------------------------------
+// Shading pieces of RayOperations.GetRayColor / PointLight.calculateLight
+// ------------------------------------------------------------------------------------------
+// RaytracingOperations.cs:88-116
+SRT_HD int depth_heuristic(int depth, float smoothness)
+{
+    if (smoothness < 0.6f) depth -= (int)((float)depth / 4.0f);
+    if (smoothness < 0.4f) depth -= (int)((float)depth / 2.0f);
+    if (smoothness < 0.2f) depth -= (int)((float)depth / 2.0f);
+    if (smoothness <= 0.05f) depth = 1;
+    return depth < 1 ? 1 : (depth > 999999 ? 999999 : depth);
+}
+// RaytracingOperations.cs:192-193
+SRT_HD f3 sky_color(float dir_y)
+{
+    float t = 0.5f * (dir_y + 1.0f);
+    float s = 1.0f - t;
+    return mk3(0.2f * t + 0.25f * s, 0.17f * t + 0.22f * s, 0.17f * t + 0.23f * s);
+}
+// CustomVectorMath.AngleBetween / 180, squared (MiscFunctions.cs:53-60, RaytracingOperations.cs:137-140)
+SRT_HD float fresnel_term(f3 dir, f3 reflected)
+{
+    float dt = dot3(dir, reflected);
+    f3 c = cross3(dir, reflected);
+    float len = sqrt_rn((c.x * c.x) + (c.y * c.y) + (c.z * c.z));
+    float angle = (float)(3.14159265358979323846 - atan2((double)len, (double)dt));
+    float deg = (float)((double)angle * 57.295779513082320876798154814105);
+    float f = deg / 180.0f;
+    return f * f;
+}
+
+struct Light { f3 position; float brightness; f3 color; };
+SRT_HD Light load_light(const SceneView& sc, uint32_t i)
+{
+    q4 a = sc.lights[2 * i], b = sc.lights[2 * i + 1];
+    Light l;
+    l.position = mk3(a.x, a.y, a.z); l.brightness = a.w; l.color = mk3(b.x, b.y, b.z);
+    return l;
+}
+
+// Direction of the shadow ray of light `li` from hit point P (RaytracingClasses.cs:105,174):
+// Normalize(position - P) + ranged(0.95), normalised again by the CustomRay constructor.
+SRT_HD f3 shadow_direction(const Light& L, f3 P, const RngKey& key, uint32_t li)
+{
+    f3 to_light = normalize3(sub3(L.position, P));
+    f3 j = random_ranged_vector(key, SLOT_LIGHT0 + li, 0.95f);
+    return normalize3(add3(to_light, j));
+}
+
+// PointLight.calculateLight, GGX branch (RaytracingClasses.cs:96-188), evaluated after its
+// shadow ray came back.  `former` is formerLightLevel; shadow_hit/t_s/P_s/metal_s describe
+// what the shadow ray's closest-hit query left in `record` (the occluder), metal_s being the
+// primary material's metalness when the shadow ray hit nothing.
+SRT_HD f3 point_light(const Light& L, f3 P, f3 N, f3 dir, const Material& m, f3 former, bool shadow_hit, float t_s, f3 P_s, float metal_s)
+{
+    float roughness = 1.0f - m.smoothness;
+    float r2 = roughness * roughness;
+    float att = clampf(1.0f / distsq3(P, L.position), 0.0f, 1.0f);
+    f3 to_light = normalize3(sub3(L.position, P));
+    f3 view = normalize3(neg3(dir));
+    f3 half = normalize3(add3(to_light, view));
+    float NdotL = clampf(dot3(N, to_light), 0.0f, 1.0f);
+    float NdotV = clampf(dot3(N, view), 0.0f, 1.0f);
+    float LdotH = clampf(dot3(to_light, half), 0.0f, 1.0f);
+    float NdotH = clampf(dot3(N, half), 0.0f, 1.0f);
+
+    float NdotL2 = NdotL * NdotL, NdotV2 = NdotV * NdotV;
+    float smithL = 2.0f / (1.0f + sqrt_rn(1.0f + r2 * (1.0f - NdotL2) / NdotL2));
+    float smithV = 2.0f / (1.0f + sqrt_rn(1.0f + r2 * (1.0f - NdotV2) / NdotV2));
+    float geo = smithL * smithV;
+    const float pi = 3.14159274f;  // (float)Math.PI
+    float denom = NdotH * NdotH * (r2 - 1.0f) + 1.0f;
+    float D = r2 / (pi * denom * denom);
+    double x = (double)(1.0f - LdotH);
+    double x2 = x * x;
+    float p5 = (float)(x2 * x2 * x);  // Math.Pow(1 - LdotH, 5)
+    float F = 0.5f + (1.0f - 0.5f) * p5;
+    float k = r2 / 2.0f;
+    float vis = (1.0f / (NdotL * (1.0f - k) + k)) * (1.0f / (NdotV * (1.0f - k) + k));
+    float ggx = NdotL * D * F * vis;
+    ggx *= (L.brightness / 2.0f);
+
+    f3 light_albedo = add3(m.albedo, L.color);
+    f3 diffuse = scale3(scale3(scale3(scale3(scale3(light_albedo, 1.0f - m.metalness), NdotL * NdotV), geo), L.brightness), att);
+    f3 level = add3(former, diffuse);
+
+    if (shadow_hit) {
+        // :175 -- compares squared lengths: |(P_s + t_s * Normalize(to_light)) - P_s|^2 < |position - P_s|^2
+        f3 d2 = normalize3(to_light);
+        f3 along = sub3(ray_at(P_s, d2, t_s), P_s);
+        if (lensq3(along) < lensq3(sub3(L.position, P_s))) {
+            level = former;
+            ggx = 0.0f;
+        }
+    }
+    // :185 -- Lerp((1,1,1) + lightColor, lightAlbedo, record.hitMat.metalness) / pi * ggx * attenuation
+    f3 one = mk3(1.0f + L.color.x, 1.0f + L.color.y, 1.0f + L.color.z);
+    f3 lerp = mk3(one.x + (light_albedo.x - one.x) * metal_s, one.y + (light_albedo.y - one.y) * metal_s, one.z + (light_albedo.z - one.z) * metal_s);
+    const float inv_pi = 1.0f / pi;  // Vector3 / float multiplies by the reciprocal
+    f3 spec = scale3(scale3(scale3(lerp, inv_pi), ggx), att);
+    return add3(level, spec);
+}
+
+// ------------------------------------------------------------------------------------------
+// Per-path state machine.  One lane owns one pixel at a time and walks the ray tree of each
+// of its samples depth first; every tree node costs one closest-hit query plus one shadow
+// query per light, and all of them go through the same query slot so that a wavefront always
+// traverses together whatever stage its lanes are in.
+// ------------------------------------------------------------------------------------------
+struct Camera { f3 position, lower_left, horizontal, vertical; };
+
+struct RenderArgs {
+    Camera cam;
+    int32_t width, height, samples, max_depth;
+    float color_clamp;
+    uint32_t seed;
+    int32_t mode, layout;
+    int32_t tile_w, tile_h, rank, world_size;
+    int32_t tiles_x, tiles_y;       // tile grid of the full image
+    uint32_t n_work;                // pixels (incl. padding of edge tiles) owned by this rank
+};
+
+// A parent waiting for its children (one per pending level of the recursion).
+struct Frame {
+    f3 acc;        // emission + weighted children so far
+    f3 light;      // lightColor, added last
+    f3 point;      // record.point
+    f3 refl;       // Normalize(reflectedDirection): direction of the metal and reflect children
+    float w_refl;  // (1 - metalness) * (fresnel * smoothness^2)
+    uint32_t meta; // material | child depth << 24
+};
+
+enum { STAGE_CLOSEST = 0, STAGE_SHADOW = 1, STAGE_DONE = 2 };
+enum : uint32_t { MODE_COLOR = 0u, MODE_NORMAL = 1u, MODE_DEPTH = 2u, MODE_LIGHTS = 3u };
+
+struct PathState {
+    // pixel
+    uint32_t work;      // work item index (for the output address)
+    int32_t px, py;
+    uint32_t sample;
+    f3 pix;             // vectorRayColor of Game1.cs:278
+    // query slot
+    f3 qo, qd;
+    float qtmin;
+    int32_t stage;
+    // current tree node
+    RngKey key;         // key.node = id of the node being evaluated
+    int32_t depth;      // `depth` argument of the current GetRayColor call
+    int32_t level;      // frames in use
+    // hit being lit (valid while stage == STAGE_SHADOW)
+    f3 P, N, dir;
+    uint32_t mat;
+    uint32_t li;
+    f3 former;          // formerLightLevel
+    // counters
+    uint32_t rays_path, rays_shadow, hit_nodes;
+};
+
+// Game1.cs:283-287: jittered viewport coordinates and the primary ray of sample `st.sample`.
+SRT_HD void start_sample(PathState& st, const RenderArgs& ra)
+{
+    st.key.sample = st.sample;
+    st.key.node = 0u;
+    uint32_t a, b, c, d;
+    rng_words(st.key, SLOT_JITTER, a, b, c, d);
+    float u = ((float)st.px + (float)rng_next(a, -50, 50) / 100.0f) / (float)ra.width;
+    float v = ((float)st.py + (float)rng_next(b, -50, 50) / 100.0f) / (float)ra.height;
+    const Camera& cm = ra.cam;
+    f3 dir = mk3(((cm.lower_left.x + u * cm.horizontal.x) + v * cm.vertical.x) - cm.position.x,
+                 ((cm.lower_left.y + u * cm.horizontal.y) + v * cm.vertical.y) - cm.position.y,
+                 ((cm.lower_left.z + u * cm.horizontal.z) + v * cm.vertical.z) - cm.position.z);
+    st.qo = cm.position;
+    st.qd = normalize3(dir);
+    st.qtmin = ((uint32_t)ra.mode == MODE_NORMAL || (uint32_t)ra.mode == MODE_DEPTH) ? 0.0f : 0.01f;
+    st.stage = STAGE_CLOSEST;
+    st.key.node = 1u;
+    st.depth = ra.max_depth;
+    st.level = 0;
+}
+
+// Maps a work item to its pixel.  Work items enumerate this rank's tiles (tile t belongs to
+// rank t % world_size), and inside a tile 8x8 blocks, so that the 64 lanes of a wavefront
+// start on an 8x8 pixel block.  Returns false for padding pixels of edge tiles.
+SRT_HD bool work_to_pixel(const RenderArgs& ra, uint32_t w, int32_t& x, int32_t& y, uint32_t& out_index)
+{
+    uint32_t tile_px = (uint32_t)(ra.tile_w * ra.tile_h);
+    uint32_t j = w / tile_px, rem = w - j * tile_px;
+    uint32_t t = j * (uint32_t)ra.world_size + (uint32_t)ra.rank;
+    uint32_t ty = t / (uint32_t)ra.tiles_x, tx = t - ty * (uint32_t)ra.tiles_x;
+    uint32_t sbw = (uint32_t)ra.tile_w >> 3;
+    uint32_t sb = rem >> 6, k = rem & 63u;
+    uint32_t sby = sb / sbw, sbx = sb - sby * sbw;
+    uint32_t lx = sbx * 8u + (k & 7u), ly = sby * 8u + (k >> 3);
+    x = (int32_t)(tx * (uint32_t)ra.tile_w + lx);
+    y = (int32_t)(ty * (uint32_t)ra.tile_h + ly);
+    out_index = ra.layout == 0 ? (uint32_t)x + (uint32_t)y * (uint32_t)ra.width : j * tile_px + ly * (uint32_t)ra.tile_w + lx;
+    return x < ra.width && y < ra.height && ty < (uint32_t)ra.tiles_y;
+}
+
+SRT_HD void start_pixel(PathState& st, const RenderArgs& ra, uint32_t work, int32_t x, int32_t y)
+{
+    st.work = work; st.px = x; st.py = y;
+    st.key.seed = ra.seed;
+    st.key.pixel = (uint32_t)x + (uint32_t)y * (uint32_t)ra.width;
+    st.sample = 0u;
+    st.pix = mk3(0.0f, 0.0f, 0.0f);
+    start_sample(st, ra);
+}
+
+// Game1.cs:301-306: gamma (sqrt per channel) and packing of a finished pixel.
+SRT_HD uint32_t finish_pixel(const PathState& st) { return pack_color(sqrt_rn(st.pix.x), sqrt_rn(st.pix.y), sqrt_rn(st.pix.z)); }
+
+SRT_HD void begin_light(PathState& st, const SceneView& sc)
+{
+    Light L = load_light(sc, st.li);
+    st.qo = st.P;
+    st.qd = shadow_direction(L, st.P, st.key, st.li);
+    st.qtmin = 0.001f;
+    st.stage = STAGE_SHADOW;
+}
+
+SRT_HD void begin_child(PathState& st, uint32_t child, f3 origin, f3 unit_dir, int32_t depth)
+{
+    st.key.node = st.key.node * 4u + child + 1u;
+    st.qo = origin; st.qd = unit_dir; st.qtmin = 0.01f;
+    st.depth = depth;
+    st.stage = STAGE_CLOSEST;
+}
+
+// Consumes the result of the query in the slot and advances the lane until it has a new
+// query to trace or its pixel is finished.  Returns true when the pixel is finished (st.pix
+// holds the accumulated colour).
+SRT_HD bool advance(PathState& st, const Hit& h, const SceneView& sc, const RenderArgs& ra, Frame* frames)
+{
+    f3 ret;  // value returned by the GetRayColor call that just completed
+    f3 light_color;
+
+    if (st.stage == STAGE_CLOSEST) {
+        const uint32_t mode = (uint32_t)ra.mode;
+        if (mode == MODE_NORMAL || mode == MODE_DEPTH) {
+            // RaytracingOperations.cs:11-35: the miss branch normalises the direction once more
+            if (h.prim != NO_PRIM) {
+                HitRecord r = resolve_hit(sc, h, st.qo, st.qd);
+                if (mode == MODE_NORMAL) ret = mk3(0.5f * (r.normal.x + 1.0f), 0.5f * (r.normal.y + 1.0f), 0.5f * (r.normal.z + 1.0f));
+                else {
+                    float value = sqrt_rn(distsq3(st.qo, r.point));
+                    float c = 1.0f - (0.07f * value);
+                    ret = mk3(c, c, c);
+                }
+            } else {
+                f3 dn = normalize3(st.qd);
+                float t = 0.5f * (dn.y + 1.0f);
+                if (mode == MODE_NORMAL) ret = mk3(t * 0.2f + (1.0f - t) * 0.5f, t * 0.2f + (1.0f - t) * 0.7f, t * 0.2f + (1.0f - t) * 1.0f);
+                else ret = mk3(t * 0.0f, t * 0.0f, t * 0.0f);
+            }
+            goto returned;
+        }
+        if (mode == MODE_LIGHTS) {
+            // GetLights on the primary ray (RaytracingOperations.cs:197-205)
+            if (h.prim == NO_PRIM || sc.n_lights == 0u) { ret = mk3(0.0f, 0.0f, 0.0f); goto returned; }
+        } else {
+            // RaytracingOperations.cs:82-83: depth < 1 returns black before anything is traced (only reachable
+            // for a primary ray with max_depth 0; children are cut off in the spawn step below)
+            if (st.depth < 1) { ret = mk3(0.0f, 0.0f, 0.0f); goto returned; }
+            st.rays_path++;
+            if (h.prim == NO_PRIM) { ret = sky_color(st.qd.y); goto returned; }
+            st.hit_nodes++;
+        }
+        {
+            HitRecord r = resolve_hit(sc, h, st.qo, st.qd);
+            st.P = r.point; st.N = r.normal; st.dir = st.qd; st.mat = r.material;
+            if (mode != MODE_LIGHTS) {
+                q4 mb = sc.materials[2 * r.material + 1];
+                st.depth = depth_heuristic(st.depth, mb.x);
+            }
+            st.former = mk3(0.0f, 0.0f, 0.0f);
+            st.li = 0u;
+            if (sc.n_lights != 0u) { begin_light(st, sc); return false; }
+            light_color = st.former;
+            goto spawn;
+        }
+    } else {
+        // STAGE_SHADOW: the shadow ray of light st.li came back (RaytracingClasses.cs:174-185)
+        st.rays_shadow++;
+        Material m = load_material(sc, st.mat);
+        Light L = load_light(sc, st.li);
+        bool sh = h.prim != NO_PRIM;
+        f3 P_s = st.P;
+        float metal_s = m.metalness;
+        if (sh) {
+            P_s = ray_at(st.qo, st.qd, h.t);
+            metal_s = sc.materials[2 * hit_material(sc, h)].w;
+        }
+        f3 c = point_light(L, st.P, st.N, st.dir, m, st.former, sh, h.t, P_s, metal_s);
+        st.former = add3(st.former, c);  // LightList: formerLightLevel += light.calculateLight(formerLightLevel, ...)
+        st.li++;
+        if (st.li < sc.n_lights) { begin_light(st, sc); return false; }
+        light_color = st.former;
+        if ((uint32_t)ra.mode == MODE_LIGHTS) { ret = light_color; goto returned; }
+    }
+
+spawn:
+    {
+        // RaytracingOperations.cs:119-183 for the node whose lighting just finished
+        Material m = load_material(sc, st.mat);
+        f3 hemi = random_hemisphere_vector(st.key, st.N);
+        f3 diffuse_dir = add3(st.N, hemi);
+        f3 rough = random_ranged_vector(st.key, SLOT_REFLECT, sqrt_rn(m.smoothness));
+        f3 refl = reflect3(st.dir, add3(st.N, rough));
+        float fres = fresnel_term(st.dir, refl);
+        float w_refl = (1.0f - m.metalness) * (fres * (m.smoothness * m.smoothness));
+        int32_t child_depth = st.depth - 1;
+        if (child_depth < 1) {
+            // every child returns Vector3.Zero without tracing (:82-83)
+            f3 zero = mk3(0.0f, 0.0f, 0.0f);
+            f3 wd = scale3(scale3(m.albedo, 1.0f - m.metalness), 0.7f);
+            f3 acc = add3(m.emission, mul3(wd, zero));
+            if (m.metalness != 0.0f) acc = add3(acc, mul3(scale3(m.albedo, m.metalness), zero));
+            if (m.metalness != 1.0f) acc = add3(acc, scale3(zero, w_refl));
+            acc = add3(acc, light_color);
+            ret = mk3(clampf(acc.x, 0.0f, ra.color_clamp), clampf(acc.y, 0.0f, ra.color_clamp), clampf(acc.z, 0.0f, ra.color_clamp));
+            goto returned;
+        }
+        Frame& f = frames[st.level];
+        f.acc = m.emission;
+        f.light = light_color;
+        f.point = st.P;
+        f.refl = normalize3(refl);
+        f.w_refl = w_refl;
+        f.meta = st.mat | ((uint32_t)child_depth << 24);
+        st.level++;
+        begin_child(st, 0u, st.P, normalize3(diffuse_dir), child_depth);
+        return false;
+    }
+
+returned:
+    for (;;) {
+        if (st.level == 0) {
+            // Game1.cs:295: vectorRayColor += vectorColor1 / samples  (Vector3 / float = times 1/samples)
+            float inv = 1.0f / (float)ra.samples;
+            st.pix = mk3(st.pix.x + ret.x * inv, st.pix.y + ret.y * inv, st.pix.z + ret.z * inv);
+            st.sample++;
+            if (st.sample < (uint32_t)ra.samples) { start_sample(st, ra); return false; }
+            st.stage = STAGE_DONE;
+            return true;
+        }
+        Frame& f = frames[st.level - 1];
+        uint32_t mat = f.meta & 0x00FFFFFFu;
+        int32_t child_depth = (int32_t)(f.meta >> 24);
+        Material m = load_material(sc, mat);
+        uint32_t child = (st.key.node & 3u) - 1u;  // which child just returned
+        st.key.node >>= 2;                          // back to the parent's id
+        f3 acc = f.acc;
+        uint32_t next;
+        if (child == 0u) {
+            f3 wd = scale3(scale3(m.albedo, 1.0f - m.metalness), 0.7f);
+            acc = add3(acc, mul3(wd, ret));
+            next = (m.metalness != 0.0f) ? 1u : 2u;
+        } else if (child == 1u) {
+            acc = add3(acc, mul3(scale3(m.albedo, m.metalness), ret));
+            next = (m.metalness != 1.0f) ? 2u : 3u;
+        } else {
+            acc = add3(acc, scale3(ret, f.w_refl));
+            next = 3u;
+        }
+        if (next < 3u) {
+            f.acc = acc;
+            begin_child(st, next, f.point, f.refl, child_depth);
+            return false;
+        }
+        acc = add3(acc, f.light);
+        ret = mk3(clampf(acc.x, 0.0f, ra.color_clamp), clampf(acc.y, 0.0f, ra.color_clamp), clampf(acc.z, 0.0f, ra.color_clamp));
+        st.level--;
+    }
+}
+
+}  // namespace srt
+#endif  // SRT_CORE_H

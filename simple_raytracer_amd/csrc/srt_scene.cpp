@@ -1,0 +1,555 @@
+// srt_scene.cpp -- flattens the host scene into 16-byte device words and builds the BVH.
+//
+// Two builders:
+//  * reference topology (SRT_WORLD_BVHNODE): the tree `new BVHNode(world)` produces
+//    (RaytracingClasses.cs:346-426) -- longest axis of the list bounds, ONE bubble pass with
+//    BoundingMath.boxCompare (MiscFunctions.cs:88-105), split at Count/2, lists whose bounds
+//    also contain the origin (SurfaceList.boundingBox, RaytracingClasses.cs:318-338) --
+//    linearised so that a left-to-right walk visits surfaces in the reference's order;
+//  * binned SAH (SRT_WORLD_SURFACELIST): the library's own tree with padded boxes; it only
+//    has to return every surface a linear scan could hit.
+#include "srt_scene.h"
+
+#include <algorithm>
+#include <cmath>
+#include <cstring>
+
+namespace srt {
+namespace {
+
+struct Box {
+    float mn[3], mx[3];
+};
+
+// System.Math.Min/Max for float (.NET Core 3.x): NaN propagates, -0 < +0.
+inline float net_max(float a, float b)
+{
+    if (a > b || a != a) return a;
+    if (a == b) return std::signbit(a) ? b : a;
+    return b;
+}
+inline float net_min(float a, float b)
+{
+    if (a < b || a != a) return a;
+    if (a == b) return std::signbit(a) ? a : b;
+    return b;
+}
+// BoundingMath.surroundingBox (MiscFunctions.cs:76-86)
+inline Box surrounding(const Box& b0, const Box& b1)
+{
+    Box r;
+    for (int k = 0; k < 3; k++) {
+        r.mn[k] = net_min(b0.mn[k], b1.mn[k]);
+        r.mx[k] = net_max(b0.mx[k], b1.mx[k]);
+    }
+    return r;
+}
+
+inline q4 mkq(float x, float y, float z, float w) { q4 q; q.x = x; q.y = y; q.z = z; q.w = w; return q; }
+
+struct NodeRec {
+    Box box;
+    uint32_t desc;
+};
+
+inline uint32_t leaf_desc(uint32_t first, uint32_t count) { return DESC_LEAF | ((count - 1u) << 27) | first; }
+
+// Surface.boundingBox of each primitive: Tri (RaytracingClasses.cs:649-664), Sphere (:489-495).
+void primitive_boxes(const HostScene& in, std::vector<Box>& pb)
+{
+    const uint32_t nt = in.n_tris(), ns = in.n_spheres();
+    pb.resize((size_t)nt + ns);
+    for (uint32_t i = 0; i < nt; i++) {
+        const float* p = &in.tri_pos[(size_t)i * 9];
+        Box b;
+        for (int k = 0; k < 3; k++) {
+            b.mx[k] = net_max(net_max(p[k], p[3 + k]), p[6 + k]);
+            b.mn[k] = net_min(net_min(p[k], p[3 + k]), p[6 + k]);
+        }
+        pb[i] = b;
+    }
+    for (uint32_t i = 0; i < ns; i++) {
+        const float* s = &in.sph[(size_t)i * 4];
+        Box b;
+        for (int k = 0; k < 3; k++) {
+            b.mx[k] = s[k] + s[3];
+            b.mn[k] = s[k] - s[3];
+        }
+        pb[nt + i] = b;
+    }
+}
+
+// ---------------------------------------------------------------------------------------
+// Reference-topology builder
+// ---------------------------------------------------------------------------------------
+struct ReferenceBuilder {
+    const std::vector<Box>& pb;
+    std::vector<uint32_t> ids;        // world.surfaces, permuted in place by the bubble passes
+    std::vector<NodeRec> nodes;
+    std::vector<uint32_t> leaf_order; // surfaces in left-to-right leaf order
+    uint32_t max_depth = 0;
+
+    explicit ReferenceBuilder(const std::vector<Box>& boxes) : pb(boxes) {}
+
+    // SurfaceList.boundingBox: the union runs on every iteration, the first time against a
+    // zero box, so the result always contains the origin.
+    Box list_bounds(uint32_t lo, uint32_t hi) const
+    {
+        Box bounds = pb[ids[lo]];
+        Box temp;
+        for (int k = 0; k < 3; k++) temp.mn[k] = temp.mx[k] = 0.0f;
+        for (uint32_t i = lo; i < hi; i++) {
+            if (i != lo) temp = bounds;
+            bounds = surrounding(pb[ids[i]], temp);
+        }
+        return bounds;
+    }
+    // BoundingMath.boxCompare: "centroid" = min + (min - max / 2)
+    bool box_compare(uint32_t a, uint32_t b, int axis) const
+    {
+        float ac = pb[a].mn[axis] + (pb[a].mn[axis] - pb[a].mx[axis] * (1.0f / 2.0f));
+        float bc = pb[b].mn[axis] + (pb[b].mn[axis] - pb[b].mx[axis] * (1.0f / 2.0f));
+        return ac < bc;
+    }
+    static int pick_axis(const Box& lb)
+    {
+        float sx = std::fabs(lb.mx[0] - lb.mn[0]), sy = std::fabs(lb.mx[1] - lb.mn[1]), sz = std::fabs(lb.mx[2] - lb.mn[2]);
+        if (sx > net_max(sy, sz)) return 0;
+        if (sy > net_max(sx, sz)) return 1;
+        if (sz > net_max(sx, sy)) return 2;
+        return 0;
+    }
+    Box build(uint32_t lo, uint32_t hi, const Box& lb, uint32_t slot, uint32_t depth)
+    {
+        if (depth > max_depth) max_depth = depth;
+        const uint32_t n = hi - lo;
+        const int axis = pick_axis(lb);
+        Box box;
+        if (n == 1) {
+            // left = right = the surface; the node keeps the list's (origin-inflated) bounds
+            uint32_t first = (uint32_t)leaf_order.size();
+            leaf_order.push_back(ids[lo]);
+            box = lb;
+            nodes[slot].desc = leaf_desc(first, 1);
+        } else if (n == 2) {
+            uint32_t l = ids[lo], r = ids[lo + 1];
+            if (box_compare(ids[lo], ids[lo + 1], axis)) { l = ids[lo + 1]; r = ids[lo]; }
+            uint32_t first = (uint32_t)leaf_order.size();
+            leaf_order.push_back(l);
+            leaf_order.push_back(r);
+            box = surrounding(pb[r], pb[l]);
+            nodes[slot].desc = leaf_desc(first, 2);
+        } else {
+            for (uint32_t i = lo; i + 1 < hi; i++)
+                if (box_compare(ids[i], ids[i + 1], axis)) std::swap(ids[i], ids[i + 1]);
+            uint32_t mid = lo + n / 2;
+            Box lbl = list_bounds(lo, mid), lbr = list_bounds(mid, hi);
+            uint32_t pair = (uint32_t)nodes.size();
+            nodes.resize(nodes.size() + 2);
+            Box bl = build(lo, mid, lbl, pair, depth + 1);
+            Box br = build(mid, hi, lbr, pair + 1, depth + 1);
+            box = surrounding(br, bl);
+            nodes[slot].desc = pair;
+        }
+        nodes[slot].box = box;
+        return box;
+    }
+    void run()
+    {
+        const uint32_t n = (uint32_t)pb.size();
+        ids.resize(n);
+        for (uint32_t i = 0; i < n; i++) ids[i] = i;
+        nodes.assign(2, NodeRec());  // root + one unused slot so that sibling pairs start at even indices
+        std::memset(nodes.data(), 0, sizeof(NodeRec) * 2);
+        leaf_order.reserve(n);
+        Box wb = list_bounds(0, n);  // world.Init() (Game1.cs:136)
+        build(0, n, wb, 0, 1);
+    }
+};
+
+// ---------------------------------------------------------------------------------------
+// Binned SAH builder
+// ---------------------------------------------------------------------------------------
+struct SahBuilder {
+    enum { BINS = 16, LEAF_MAX = 4, DEPTH_LIMIT = STACK_DEPTH - 2 };
+    const std::vector<Box>& pb;
+    std::vector<uint32_t> ids;
+    std::vector<float> cx[3];
+    std::vector<NodeRec> nodes;
+    std::vector<uint32_t> leaf_order;
+    uint32_t max_depth = 0;
+
+    explicit SahBuilder(const std::vector<Box>& boxes) : pb(boxes) {}
+
+    static void grow(Box& b, const Box& o)
+    {
+        for (int k = 0; k < 3; k++) {
+            b.mn[k] = std::fmin(b.mn[k], o.mn[k]);
+            b.mx[k] = std::fmax(b.mx[k], o.mx[k]);
+        }
+    }
+    static Box empty_box()
+    {
+        Box b;
+        for (int k = 0; k < 3; k++) { b.mn[k] = INFINITY; b.mx[k] = -INFINITY; }
+        return b;
+    }
+    static float half_area(const Box& b)
+    {
+        float dx = b.mx[0] - b.mn[0], dy = b.mx[1] - b.mn[1], dz = b.mx[2] - b.mn[2];
+        if (!(dx >= 0.0f) || !(dy >= 0.0f) || !(dz >= 0.0f)) return 0.0f;
+        return dx * dy + dy * dz + dz * dx;
+    }
+    static uint32_t ceil_log2(uint32_t n)
+    {
+        uint32_t l = 0;
+        while ((1u << l) < n) l++;
+        return l;
+    }
+    void make_leaf(uint32_t lo, uint32_t hi, uint32_t slot)
+    {
+        uint32_t first = (uint32_t)leaf_order.size();
+        // keep insertion order inside a leaf; ties are settled by the order rank anyway
+        std::sort(ids.begin() + lo, ids.begin() + hi);
+        for (uint32_t i = lo; i < hi; i++) leaf_order.push_back(ids[i]);
+        nodes[slot].desc = leaf_desc(first, hi - lo);
+    }
+    void build(uint32_t lo, uint32_t hi, uint32_t slot, uint32_t depth)
+    {
+        if (depth > max_depth) max_depth = depth;
+        const uint32_t n = hi - lo;
+        Box box = empty_box(), cb = empty_box();
+        for (uint32_t i = lo; i < hi; i++) {
+            grow(box, pb[ids[i]]);
+            for (int k = 0; k < 3; k++) {
+                float c = cx[k][ids[i]];
+                cb.mn[k] = std::fmin(cb.mn[k], c);
+                cb.mx[k] = std::fmax(cb.mx[k], c);
+            }
+        }
+        nodes[slot].box = box;
+        if (n <= 1) { make_leaf(lo, hi, slot); return; }
+
+        // levels still available below this node; a balanced split needs ceil_log2(n / LEAF_MAX)
+        const bool must_balance = depth + ceil_log2((n + LEAF_MAX - 1) / LEAF_MAX) + 1 >= (uint32_t)DEPTH_LIMIT;
+        uint32_t mid = 0;
+        bool split = false;
+        if (!must_balance) {
+            float best_cost = INFINITY;
+            int best_axis = -1, best_bin = -1;
+            for (int axis = 0; axis < 3; axis++) {
+                float lo_c = cb.mn[axis], ext = cb.mx[axis] - cb.mn[axis];
+                if (!(ext > 0.0f)) continue;
+                Box bb[BINS];
+                uint32_t bc[BINS];
+                for (int b = 0; b < BINS; b++) { bb[b] = empty_box(); bc[b] = 0; }
+                float scale = (float)BINS / ext;
+                for (uint32_t i = lo; i < hi; i++) {
+                    int b = (int)((cx[axis][ids[i]] - lo_c) * scale);
+                    b = b < 0 ? 0 : (b >= BINS ? BINS - 1 : b);
+                    bc[b]++;
+                    grow(bb[b], pb[ids[i]]);
+                }
+                float right_area[BINS];
+                uint32_t right_cnt[BINS];
+                Box acc = empty_box();
+                uint32_t cnt = 0;
+                for (int b = BINS - 1; b > 0; b--) {
+                    grow(acc, bb[b]);
+                    cnt += bc[b];
+                    right_area[b] = half_area(acc);
+                    right_cnt[b] = cnt;
+                }
+                acc = empty_box();
+                cnt = 0;
+                for (int b = 0; b < BINS - 1; b++) {
+                    grow(acc, bb[b]);
+                    cnt += bc[b];
+                    if (cnt == 0 || right_cnt[b + 1] == 0) continue;
+                    float cost = half_area(acc) * (float)cnt + right_area[b + 1] * (float)right_cnt[b + 1];
+                    if (cost < best_cost) { best_cost = cost; best_axis = axis; best_bin = b; }
+                }
+            }
+            if (best_axis >= 0) {
+                float leaf_cost = half_area(box) * (float)n;
+                float split_cost = 1.0f * half_area(box) + best_cost;  // one box-pair visit ~ one primitive test
+                if (n > (uint32_t)LEAF_MAX || split_cost < leaf_cost) {
+                    float lo_c = cb.mn[best_axis], ext = cb.mx[best_axis] - cb.mn[best_axis];
+                    float scale = (float)BINS / ext;
+                    auto it = std::partition(ids.begin() + lo, ids.begin() + hi, [&](uint32_t id) {
+                        int b = (int)((cx[best_axis][id] - lo_c) * scale);
+                        b = b < 0 ? 0 : (b >= BINS ? BINS - 1 : b);
+                        return b <= best_bin;
+                    });
+                    mid = (uint32_t)(it - ids.begin());
+                    split = mid > lo && mid < hi;
+                }
+            }
+        }
+        if (!split) {
+            if (n <= (uint32_t)LEAF_MAX) { make_leaf(lo, hi, slot); return; }
+            // object median along the widest centroid axis (also the forced balanced split)
+            int axis = 0;
+            float e0 = cb.mx[0] - cb.mn[0], e1 = cb.mx[1] - cb.mn[1], e2 = cb.mx[2] - cb.mn[2];
+            if (e1 > e0 && e1 >= e2) axis = 1;
+            else if (e2 > e0 && e2 > e1) axis = 2;
+            mid = lo + n / 2;
+            std::nth_element(ids.begin() + lo, ids.begin() + mid, ids.begin() + hi,
+                             [&](uint32_t a, uint32_t b) { return cx[axis][a] < cx[axis][b] || (cx[axis][a] == cx[axis][b] && a < b); });
+        }
+        uint32_t pair = (uint32_t)nodes.size();
+        nodes.resize(nodes.size() + 2);
+        nodes[slot].desc = pair;
+        build(lo, mid, pair, depth + 1);
+        build(mid, hi, pair + 1, depth + 1);
+    }
+    void run()
+    {
+        const uint32_t n = (uint32_t)pb.size();
+        ids.resize(n);
+        for (int k = 0; k < 3; k++) cx[k].resize(n);
+        for (uint32_t i = 0; i < n; i++) {
+            ids[i] = i;
+            for (int k = 0; k < 3; k++) cx[k][i] = 0.5f * pb[i].mn[k] + 0.5f * pb[i].mx[k];
+        }
+        nodes.assign(2, NodeRec());
+        std::memset(nodes.data(), 0, sizeof(NodeRec) * 2);
+        leaf_order.reserve(n);
+        build(0, n, 0, 1);
+        // Pad every box: the slab test and the primitive tests round differently, and a ray
+        // that a primitive test accepts must never be culled by a box.
+        float ext = 0.0f;
+        for (int k = 0; k < 3; k++) {
+            ext = std::fmax(ext, nodes[0].box.mx[k] - nodes[0].box.mn[k]);
+            ext = std::fmax(ext, std::fmax(std::fabs(nodes[0].box.mx[k]), std::fabs(nodes[0].box.mn[k])));
+        }
+        float pad = ext * (1.0f / 65536.0f);
+        if (!(pad > 0.0f)) pad = 1e-6f;
+        for (auto& nd : nodes)
+            for (int k = 0; k < 3; k++) { nd.box.mn[k] -= pad; nd.box.mx[k] += pad; }
+    }
+};
+
+// primitive record for global surface index `g`
+void emit_prim(const HostScene& in, uint32_t g, uint32_t order, std::vector<q4>& prims)
+{
+    const uint32_t nt = in.n_tris(), ns = in.n_spheres();
+    if (g < nt) {
+        const float* p = &in.tri_pos[(size_t)g * 9];
+        // Tri constructor (RaytracingClasses.cs:561-562): AB = B - A, AC = C - A
+        float ab[3] = {p[3] - p[0], p[4] - p[1], p[5] - p[2]};
+        float ac[3] = {p[6] - p[0], p[7] - p[1], p[8] - p[2]};
+        uint8_t fl = in.tri_flags[g];
+        uint32_t info = PRIM_TRI | ((fl & 1u) ? (uint32_t)INFO_FLIP : 0u) | ((fl & 2u) ? (uint32_t)INFO_BLEND : 0u) | (in.tri_mat[g] << 8);
+        prims.push_back(mkq(p[0], p[1], p[2], ab[0]));
+        prims.push_back(mkq(ab[1], ab[2], ac[0], ac[1]));
+        prims.push_back(mkq(ac[2], bitsf(info), bitsf(order), bitsf(g)));
+    } else if (g < nt + ns) {
+        uint32_t i = g - nt;
+        const float* s = &in.sph[(size_t)i * 4];
+        uint32_t info = PRIM_SPHERE | (in.sph_mat[i] << 8);
+        prims.push_back(mkq(s[0], s[1], s[2], s[3]));
+        prims.push_back(mkq(0, 0, 0, 0));
+        prims.push_back(mkq(0, bitsf(info), bitsf(order), 0));
+    } else {
+        uint32_t i = g - nt - ns;
+        const float* r = &in.rect[(size_t)i * 5];
+        uint32_t info = PRIM_RECT | (in.rect_mat[i] << 8);
+        prims.push_back(mkq(r[0], r[1], r[2], r[3]));
+        prims.push_back(mkq(r[4], 0, 0, 0));
+        prims.push_back(mkq(0, bitsf(info), bitsf(order), 0));
+    }
+}
+
+void emit_nodes(const std::vector<NodeRec>& nodes, std::vector<q4>& out)
+{
+    out.reserve(nodes.size() * 2);
+    for (const NodeRec& n : nodes) {
+        out.push_back(mkq(n.box.mn[0], n.box.mn[1], n.box.mn[2], bitsf(n.desc)));
+        out.push_back(mkq(n.box.mx[0], n.box.mx[1], n.box.mx[2], 0.0f));
+    }
+}
+
+}  // namespace
+
+int host_set_materials(HostScene& s, const srt_material* m, uint32_t n, std::string& err)
+{
+    if (n && !m) { err = "materials is NULL"; return SRT_E_INVALID; }
+    s.materials.assign(m, m + n);
+    return SRT_OK;
+}
+
+int host_set_spheres(HostScene& s, const float* cx, const float* cy, const float* cz, const float* r, const uint32_t* mat, uint32_t n, std::string& err)
+{
+    if (n && (!cx || !cy || !cz || !r || !mat)) { err = "sphere array is NULL"; return SRT_E_INVALID; }
+    s.sph.resize((size_t)n * 4);
+    s.sph_mat.assign(mat, mat + n);
+    for (uint32_t i = 0; i < n; i++) {
+        s.sph[(size_t)i * 4 + 0] = cx[i]; s.sph[(size_t)i * 4 + 1] = cy[i];
+        s.sph[(size_t)i * 4 + 2] = cz[i]; s.sph[(size_t)i * 4 + 3] = r[i];
+    }
+    return SRT_OK;
+}
+
+int host_set_rects(HostScene& s, const float* x1, const float* x2, const float* y1, const float* y2, const float* k, const uint32_t* mat, uint32_t n, std::string& err)
+{
+    if (n && (!x1 || !x2 || !y1 || !y2 || !k || !mat)) { err = "rect array is NULL"; return SRT_E_INVALID; }
+    s.rect.resize((size_t)n * 5);
+    s.rect_mat.assign(mat, mat + n);
+    for (uint32_t i = 0; i < n; i++) {
+        float* d = &s.rect[(size_t)i * 5];
+        d[0] = x1[i]; d[1] = x2[i]; d[2] = y1[i]; d[3] = y2[i]; d[4] = k[i];
+    }
+    return SRT_OK;
+}
+
+int host_set_triangles(HostScene& s, const float* pos9, const float* nrm9, const uint32_t* mat, const uint8_t* flags, uint32_t n, std::string& err)
+{
+    if (n && (!pos9 || !nrm9 || !mat)) { err = "triangle array is NULL"; return SRT_E_INVALID; }
+    s.tri_pos.assign(pos9, pos9 + (size_t)n * 9);
+    s.tri_nrm.assign(nrm9, nrm9 + (size_t)n * 9);
+    s.tri_mat.assign(mat, mat + n);
+    if (flags) s.tri_flags.assign(flags, flags + n);
+    else s.tri_flags.assign(n, (uint8_t)2);  // flip = false, blend = true (ModelLoader.cs:60)
+    return SRT_OK;
+}
+
+int host_set_lights(HostScene& s, const srt_point_light* l, uint32_t n, std::string& err)
+{
+    if (n && !l) { err = "lights is NULL"; return SRT_E_INVALID; }
+    if (n > SRT_MAX_LIGHTS) { err = "too many lights"; return SRT_E_LIMIT; }
+    s.lights.assign(l, l + n);
+    return SRT_OK;
+}
+
+static int check_params(const srt_render_params* p, int& tw, int& th, int& world, std::string* err)
+{
+    auto fail = [&](int code, const char* msg) { if (err) *err = msg; return code; };
+    if (!p) return fail(SRT_E_INVALID, "params is NULL");
+    if (p->width <= 0 || p->height <= 0 || p->samples <= 0) return fail(SRT_E_INVALID, "width, height and samples must be positive");
+    if ((int64_t)p->width * p->height >= (int64_t)1 << 31) return fail(SRT_E_LIMIT, "image has 2^31 pixels or more");
+    if (p->max_depth < 0 || p->max_depth > SRT_MAX_DEPTH) return fail(SRT_E_LIMIT, "max_depth must be within 0..SRT_MAX_DEPTH");
+    if (p->color_clamp != p->color_clamp) return fail(SRT_E_INVALID, "color_clamp is NaN");
+    if (p->color_clamp < 0) return fail(SRT_E_REFERENCE, "Math.Clamp(x, 0, clamp) throws ArgumentException when clamp < 0");
+    if (p->mode < SRT_MODE_COLOR || p->mode > SRT_MODE_LIGHTS) return fail(SRT_E_INVALID, "unknown mode");
+    if (p->layout != SRT_LAYOUT_FRAME && p->layout != SRT_LAYOUT_TILES) return fail(SRT_E_INVALID, "unknown layout");
+    tw = p->tile_w ? p->tile_w : 32;
+    th = p->tile_h ? p->tile_h : 32;
+    if (tw <= 0 || th <= 0 || (tw & 7) || (th & 7) || tw > 4096 || th > 4096) return fail(SRT_E_INVALID, "tile size must be a positive multiple of 8");
+    world = p->world_size > 1 ? p->world_size : 1;
+    if (p->rank < 0 || p->rank >= world) return fail(SRT_E_INVALID, "rank out of range");
+    return SRT_OK;
+}
+
+static int64_t local_tiles(const srt_render_params* p, int tw, int th, int world)
+{
+    int64_t tx = (p->width + tw - 1) / tw, ty = (p->height + th - 1) / th;
+    int64_t total = tx * ty;
+    return total > p->rank ? (total - p->rank + world - 1) / world : 0;
+}
+
+int64_t output_pixels(const srt_render_params* p)
+{
+    int tw, th, world;
+    int rc = check_params(p, tw, th, world, nullptr);
+    if (rc != SRT_OK) return rc;
+    if (p->layout == SRT_LAYOUT_FRAME) return (int64_t)p->width * p->height;
+    return local_tiles(p, tw, th, world) * tw * th;
+}
+
+int make_render_args(const srt_render_params* p, const Camera& cam, RenderArgs& ra, std::string& err)
+{
+    int tw, th, world;
+    int rc = check_params(p, tw, th, world, &err);
+    if (rc != SRT_OK) return rc;
+    ra.cam = cam;
+    ra.width = p->width; ra.height = p->height; ra.samples = p->samples; ra.max_depth = p->max_depth;
+    ra.color_clamp = p->color_clamp; ra.seed = p->seed; ra.mode = p->mode; ra.layout = p->layout;
+    ra.tile_w = tw; ra.tile_h = th; ra.rank = p->rank; ra.world_size = world;
+    ra.tiles_x = (p->width + tw - 1) / tw;
+    ra.tiles_y = (p->height + th - 1) / th;
+    int64_t work = local_tiles(p, tw, th, world) * tw * th;
+    if (work >= ((int64_t)1 << 32)) { err = "more than 2^32 work items"; return SRT_E_LIMIT; }
+    ra.n_work = (uint32_t)work;
+    return SRT_OK;
+}
+
+int flatten_scene(const HostScene& in, int world_kind, FlatScene& out, std::string& err)
+{
+    out = FlatScene();
+    const uint32_t nt = in.n_tris(), ns = in.n_spheres(), nr = in.n_rects();
+    const uint64_t total = (uint64_t)nt + ns + nr;
+    if (total >= (1u << 27)) { err = "more than 2^27 surfaces"; return SRT_E_LIMIT; }
+    if (in.materials.size() >= (1u << 24)) { err = "more than 2^24 materials"; return SRT_E_LIMIT; }
+    if (in.lights.size() > SRT_MAX_LIGHTS) { err = "too many lights"; return SRT_E_LIMIT; }
+    const uint32_t nm = (uint32_t)in.materials.size();
+    for (uint32_t m : in.tri_mat) if (m >= nm) { err = "triangle material index out of range"; return SRT_E_INVALID; }
+    for (uint32_t m : in.sph_mat) if (m >= nm) { err = "sphere material index out of range"; return SRT_E_INVALID; }
+    for (uint32_t m : in.rect_mat) if (m >= nm) { err = "rect material index out of range"; return SRT_E_INVALID; }
+    if (world_kind != SRT_WORLD_BVHNODE && world_kind != SRT_WORLD_SURFACELIST) { err = "unknown world kind"; return SRT_E_INVALID; }
+    if (world_kind == SRT_WORLD_BVHNODE && nr > 0) {
+        err = "RectAxis has no boundingBox(): new BVHNode(world) throws NullReferenceException in the reference; use SRT_WORLD_SURFACELIST";
+        return SRT_E_REFERENCE;
+    }
+
+    for (const srt_material& m : in.materials) {
+        out.materials.push_back(mkq(m.albedo[0], m.albedo[1], m.albedo[2], m.metalness));
+        out.materials.push_back(mkq(m.smoothness, m.emission[0], m.emission[1], m.emission[2]));
+    }
+    for (const srt_point_light& l : in.lights) {
+        out.lights.push_back(mkq(l.position[0], l.position[1], l.position[2], l.brightness));
+        out.lights.push_back(mkq(l.color[0], l.color[1], l.color[2], 0.0f));
+    }
+    out.n_lights = (uint32_t)in.lights.size();
+    out.normals.reserve((size_t)nt * 3);
+    for (uint32_t i = 0; i < nt; i++) {
+        const float* n = &in.tri_nrm[(size_t)i * 9];
+        out.normals.push_back(mkq(n[0], n[1], n[2], 0.0f));
+        out.normals.push_back(mkq(n[3], n[4], n[5], 0.0f));
+        out.normals.push_back(mkq(n[6], n[7], n[8], 0.0f));
+    }
+    out.n_prims = (uint32_t)total;
+    out.prims.reserve((size_t)total * 3);
+
+    const uint32_t n_boxed = nt + ns;
+    const bool tiny = world_kind == SRT_WORLD_SURFACELIST && n_boxed <= 8;
+    if (n_boxed > 0 && !tiny) {
+        std::vector<Box> pb;
+        primitive_boxes(in, pb);
+        if (world_kind == SRT_WORLD_BVHNODE) {
+            ReferenceBuilder b(pb);
+            b.run();
+            for (uint32_t i = 0; i < b.leaf_order.size(); i++) emit_prim(in, b.leaf_order[i], i, out.prims);
+            emit_nodes(b.nodes, out.nodes);
+            out.n_nodes = (uint32_t)b.nodes.size();
+            out.bvh_depth = b.max_depth;
+        } else {
+            SahBuilder b(pb);
+            b.run();
+            for (uint32_t i = 0; i < b.leaf_order.size(); i++) emit_prim(in, b.leaf_order[i], b.leaf_order[i], out.prims);
+            emit_nodes(b.nodes, out.nodes);
+            out.n_nodes = (uint32_t)b.nodes.size();
+            out.bvh_depth = b.max_depth;
+        }
+        if (out.bvh_depth > (uint32_t)STACK_DEPTH) { err = "BVH deeper than the traversal stack"; return SRT_E_LIMIT; }
+        out.has_bvh = 1;
+        out.list_first = n_boxed;
+        for (uint32_t i = 0; i < nr; i++) emit_prim(in, n_boxed + i, n_boxed + i, out.prims);
+        out.list_count = nr;
+    } else {
+        for (uint32_t g = 0; g < (uint32_t)total; g++) emit_prim(in, g, g, out.prims);
+        out.list_first = 0;
+        out.list_count = (uint32_t)total;
+        out.has_bvh = 0;
+    }
+    // never hand the device an empty allocation
+    q4 zero = mkq(0, 0, 0, 0);
+    if (out.nodes.empty()) out.nodes.assign(2, zero);
+    if (out.prims.empty()) out.prims.assign(3, zero);
+    if (out.normals.empty()) out.normals.assign(3, zero);
+    if (out.materials.empty()) out.materials.assign(2, zero);
+    if (out.lights.empty()) out.lights.assign(2, zero);
+    return SRT_OK;
+}
+
+}  // namespace srt

@@ -1,0 +1,55 @@
+// srt_scene.h -- host-side scene flattening and BVH construction (no HIP calls).
+#ifndef SRT_SCENE_H
+#define SRT_SCENE_H
+
+#include <stdint.h>
+#include <string>
+#include <vector>
+
+#include "../../include/srt.h"
+#include "srt_core.h"
+
+namespace srt {
+
+// What the srt_set_* calls copied from the caller: the reference's world.surfaces /
+// lights.lights / materials, by type.  Global surface index ("insertion order"):
+// triangles first, then spheres, then rects.
+struct HostScene {
+    std::vector<srt_material> materials;
+    std::vector<float> tri_pos, tri_nrm;  // 9 floats per triangle
+    std::vector<uint32_t> tri_mat;
+    std::vector<uint8_t> tri_flags;       // bit0 flip, bit1 blend
+    std::vector<float> sph;               // cx cy cz r
+    std::vector<uint32_t> sph_mat;
+    std::vector<float> rect;              // x1 x2 y1 y2 k
+    std::vector<uint32_t> rect_mat;
+    std::vector<srt_point_light> lights;
+    uint32_t n_tris() const { return (uint32_t)tri_mat.size(); }
+    uint32_t n_spheres() const { return (uint32_t)sph_mat.size(); }
+    uint32_t n_rects() const { return (uint32_t)rect_mat.size(); }
+};
+
+// Device-ready arrays in the layout srt_core.h documents.
+struct FlatScene {
+    std::vector<q4> nodes, prims, normals, materials, lights;
+    uint32_t n_lights = 0, list_first = 0, list_count = 0, has_bvh = 0;
+    uint32_t n_nodes = 0, bvh_depth = 0, n_prims = 0;
+};
+
+// Returns SRT_OK or a negative SRT_E_* code with `err` set.
+int flatten_scene(const HostScene& in, int world_kind, FlatScene& out, std::string& err);
+
+// Argument checking + copying behind the srt_set_* entry points.
+int host_set_materials(HostScene& s, const srt_material* m, uint32_t n, std::string& err);
+int host_set_spheres(HostScene& s, const float* cx, const float* cy, const float* cz, const float* r, const uint32_t* mat, uint32_t n, std::string& err);
+int host_set_rects(HostScene& s, const float* x1, const float* x2, const float* y1, const float* y2, const float* k, const uint32_t* mat, uint32_t n, std::string& err);
+int host_set_triangles(HostScene& s, const float* pos9, const float* nrm9, const uint32_t* mat, const uint8_t* flags, uint32_t n, std::string& err);
+int host_set_lights(HostScene& s, const srt_point_light* l, uint32_t n, std::string& err);
+
+// Validates render parameters and derives the kernel arguments (tile grid, work item count).
+int make_render_args(const srt_render_params* p, const Camera& cam, RenderArgs& ra, std::string& err);
+// Pixels in the output buffer for these parameters, or a negative SRT_E_* code.
+int64_t output_pixels(const srt_render_params* p);
+
+}  // namespace srt
+#endif

@@ -1,0 +1,141 @@
+// emu_api.cpp -- TEST HARNESS, not part of the product.
+//
+// Runs the device code of simple_raytracer_amd/csrc/srt_core.h (the per-lane state machine, the
+// traversal and the shading) and the host-side scene flattening of srt_scene.cpp on the CPU,
+// one lane at a time, behind the same C ABI as libsrt.so.  It lets the CPU test-suite compare
+// the kernel logic with the oracle in a container that has no GPU.  libsrt.so contains none
+// of this; its renders always run on the device.
+#include <cstring>
+#include <string>
+#include <thread>
+#include <vector>
+
+#include "../../include/srt.h"
+#include "../../simple_raytracer_amd/csrc/srt_core.h"
+#include "../../simple_raytracer_amd/csrc/srt_scene.h"
+
+using namespace srt;
+
+struct srt_ctx {
+    HostScene host;
+    FlatScene flat;
+    bool committed = false;
+    int world_kind = 0;
+    Camera cam{};
+    bool has_camera = false;
+    srt_stats stats{};
+    std::string error;
+};
+
+namespace {
+
+struct Totals { uint64_t v[7] = {0, 0, 0, 0, 0, 0, 0}; };
+
+template <bool EXACT>
+void run_range(const SceneView& sc, const RenderArgs& ra, uint32_t w0, uint32_t w1, uint32_t* out, Totals* tot)
+{
+    std::vector<uint32_t> stack(STACK_DEPTH);
+    Counters cnt{0, 0, 0, 0};
+    for (uint32_t work = w0; work < w1; work++) {
+        int32_t x, y;
+        uint32_t oi;
+        if (!work_to_pixel(ra, work, x, y, oi)) {
+            if (ra.layout != 0) out[oi] = 0u;
+            continue;
+        }
+        PathState st;
+        Frame frames[FRAME_SLOTS];
+        st.rays_path = st.rays_shadow = st.hit_nodes = 0u;
+        start_pixel(st, ra, oi, x, y);
+        for (;;) {
+            Hit h = closest_hit<EXACT, true, 1>(sc, st.qo, st.qd, st.qtmin, stack.data(), cnt);
+            if (advance(st, h, sc, ra, frames)) break;
+        }
+        out[st.work] = finish_pixel(st);
+        tot->v[0] += st.rays_path; tot->v[1] += st.rays_shadow; tot->v[2] += st.hit_nodes;
+    }
+    tot->v[3] += cnt.box_tests; tot->v[4] += cnt.sphere_tests; tot->v[5] += cnt.tri_tests; tot->v[6] += cnt.rect_tests;
+}
+
+}  // namespace
+
+extern "C" {
+
+int srt_version(void) { return SRT_VERSION; }
+const char* srt_last_error(const srt_ctx* c) { return c ? c->error.c_str() : ""; }
+int srt_create(const srt_config*, srt_ctx** out) { *out = new srt_ctx(); return SRT_OK; }
+void srt_destroy(srt_ctx* c) { delete c; }
+
+int srt_set_camera(srt_ctx* c, const float p[3], const float l[3], const float h[3], const float v[3])
+{
+    c->cam.position = mk3(p[0], p[1], p[2]); c->cam.lower_left = mk3(l[0], l[1], l[2]);
+    c->cam.horizontal = mk3(h[0], h[1], h[2]); c->cam.vertical = mk3(v[0], v[1], v[2]);
+    c->has_camera = true;
+    return SRT_OK;
+}
+int srt_set_materials(srt_ctx* c, const srt_material* m, uint32_t n) { c->committed = false; return host_set_materials(c->host, m, n, c->error); }
+int srt_set_spheres(srt_ctx* c, const float* cx, const float* cy, const float* cz, const float* r, const uint32_t* mat, uint32_t n)
+{
+    c->committed = false;
+    return host_set_spheres(c->host, cx, cy, cz, r, mat, n, c->error);
+}
+int srt_set_rects(srt_ctx* c, const float* x1, const float* x2, const float* y1, const float* y2, const float* k, const uint32_t* mat, uint32_t n)
+{
+    c->committed = false;
+    return host_set_rects(c->host, x1, x2, y1, y2, k, mat, n, c->error);
+}
+int srt_set_triangles(srt_ctx* c, const float* pos9, const float* nrm9, const uint32_t* mat, const uint8_t* flags, uint32_t n)
+{
+    c->committed = false;
+    return host_set_triangles(c->host, pos9, nrm9, mat, flags, n, c->error);
+}
+int srt_set_lights(srt_ctx* c, const srt_point_light* l, uint32_t n) { c->committed = false; return host_set_lights(c->host, l, n, c->error); }
+
+int srt_commit_scene(srt_ctx* c, int world_kind)
+{
+    c->committed = false;
+    int rc = flatten_scene(c->host, world_kind, c->flat, c->error);
+    if (rc != SRT_OK) return rc;
+    c->world_kind = world_kind;
+    c->committed = true;
+    c->stats.bvh_nodes = c->flat.n_nodes; c->stats.bvh_depth = c->flat.bvh_depth; c->stats.n_prims = c->flat.n_prims;
+    return SRT_OK;
+}
+
+int srt_render(srt_ctx* c, const srt_render_params* p, uint32_t* out)
+{
+    if (!c->committed || !c->has_camera) { c->error = "scene or camera missing"; return SRT_E_STATE; }
+    RenderArgs ra;
+    int rc = make_render_args(p, c->cam, ra, c->error);
+    if (rc != SRT_OK) return rc;
+    SceneView sc;
+    sc.nodes = c->flat.nodes.data(); sc.prims = c->flat.prims.data(); sc.normals = c->flat.normals.data();
+    sc.materials = c->flat.materials.data(); sc.lights = c->flat.lights.data();
+    sc.n_lights = c->flat.n_lights; sc.list_first = c->flat.list_first; sc.list_count = c->flat.list_count; sc.has_bvh = c->flat.has_bvh;
+    unsigned n = std::thread::hardware_concurrency();
+    if (n < 1) n = 1;
+    std::vector<Totals> tot(n);
+    std::vector<std::thread> pool;
+    const bool exact = c->world_kind == SRT_WORLD_BVHNODE;
+    // interleave chunks of 64 work items over the threads
+    for (unsigned t = 0; t < n; t++) {
+        pool.emplace_back([&, t]() {
+            for (uint64_t w0 = (uint64_t)t * 64; w0 < ra.n_work; w0 += (uint64_t)n * 64) {
+                uint32_t w1 = (uint32_t)std::min<uint64_t>(w0 + 64, ra.n_work);
+                if (exact) run_range<true>(sc, ra, (uint32_t)w0, w1, out, &tot[t]);
+                else run_range<false>(sc, ra, (uint32_t)w0, w1, out, &tot[t]);
+            }
+        });
+    }
+    for (auto& th : pool) th.join();
+    uint64_t s[7] = {0, 0, 0, 0, 0, 0, 0};
+    for (auto& t : tot) for (int i = 0; i < 7; i++) s[i] += t.v[i];
+    c->stats.rays_path = s[0]; c->stats.rays_shadow = s[1]; c->stats.hit_nodes = s[2];
+    c->stats.box_tests = s[3]; c->stats.sphere_tests = s[4]; c->stats.tri_tests = s[5]; c->stats.rect_tests = s[6];
+    return SRT_OK;
+}
+int srt_render_counted(srt_ctx* c, const srt_render_params* p, uint32_t* out) { return srt_render(c, p, out); }
+int srt_get_stats(srt_ctx* c, srt_stats* out) { *out = c->stats; return SRT_OK; }
+int64_t srt_local_pixels(const srt_render_params* p) { return output_pixels(p); }
+
+}  // extern "C"

@@ -1,0 +1,45 @@
+"""Writes tests/golden/*.npz: images rendered by the CPU oracle on fixed seeds.
+
+The reference program has no golden vectors of its own, so these are outputs of the oracle (see
+oracle/srt_oracle.cpp).  They make two checks possible without re-running anything: that a later oracle
+build still produces them (CPU suite), and that the GPU library produces them on a machine that has
+neither the oracle's sources nor the reference (GPU suite).
+
+Run from the repository root:  python tests/golden/make_golden.py
+"""
+import os
+import sys
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, os.path.dirname(HERE))
+import helpers  # noqa: E402
+from oracle import orc  # noqa: E402
+
+# name -> (spec factory name, kwargs, width, height, samples, max_depth, mode, world_kind, seed)
+GOLDEN = {
+    "default_normal_64x36": ("default_spec", {}, 64, 36, 1, 4, orc.MODE_NORMAL, orc.WORLD_BVHNODE, 1),
+    "default_depth_64x36": ("default_spec", {}, 64, 36, 1, 4, orc.MODE_DEPTH, orc.WORLD_BVHNODE, 1),
+    "default_color_1spp_64x36": ("default_spec", {}, 64, 36, 1, 4, orc.MODE_COLOR, orc.WORLD_BVHNODE, 1),
+    "default_color_16spp_64x36": ("default_spec", {}, 64, 36, 16, 4, orc.MODE_COLOR, orc.WORLD_BVHNODE, 1),
+    "default_color_4spp_d8_64x36": ("default_spec", {}, 64, 36, 4, 8, orc.MODE_COLOR, orc.WORLD_BVHNODE, 1),
+    "default_rect_list_2spp_64x36": ("default_spec", {"with_rect": True}, 64, 36, 2, 4, orc.MODE_COLOR, orc.WORLD_SURFACELIST, 1),
+    "mesh_color_1spp_bvhnode_64x36": ("mesh_spec", {"n": 10}, 64, 36, 1, 4, orc.MODE_COLOR, orc.WORLD_BVHNODE, 1),
+    "mesh_color_4spp_list_64x36": ("mesh_spec", {"n": 10, "with_rect": True}, 64, 36, 4, 6, orc.MODE_COLOR, orc.WORLD_SURFACELIST, 1),
+}
+
+
+def render(entry):
+    factory, kwargs, w, h, spp, depth, mode, kind, seed = entry
+    spec = getattr(helpers, factory)(**kwargs)
+    img, st, nodes = spec.oracle_scene().render(spec.oracle_camera(w, h), w, h, samples=spp, max_depth=depth, seed=seed,
+                                                mode=mode, world_kind=kind, want_nodes=True)
+    return img, nodes, np.array([st["rays_path"], st["rays_shadow"], st["hit_nodes"]], dtype=np.uint64)
+
+
+if __name__ == "__main__":
+    for name, entry in GOLDEN.items():
+        img, nodes, counts = render(entry)
+        np.savez_compressed(os.path.join(HERE, name + ".npz"), image=img, nodes_per_pixel=nodes, counts=counts)
+        print(name, img.shape, counts.tolist())

@@ -1,0 +1,183 @@
+"""Shared test helpers: one scene description, turned into oracle inputs and into host-mirror objects."""
+import os
+import subprocess
+import sys
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+from oracle import orc  # noqa: E402  (test infrastructure)
+import simple_raytracer_amd as srt  # noqa: E402
+from simple_raytracer_amd import game1  # noqa: E402
+
+EMU_DIR = os.path.join(ROOT, "tests", "emu")
+EMU_LIB = os.path.join(EMU_DIR, "libsrt_emu.so")
+GOLDEN = os.path.join(ROOT, "tests", "golden")
+
+
+def build_emu():
+    """Compiles the CPU harness of the kernel source (tests/emu)."""
+    subprocess.check_call(["make", "-C", EMU_DIR, "-s"])
+    return EMU_LIB
+
+
+class SceneSpec:
+    """Materials / surfaces / lights / camera in plain numbers."""
+
+    def __init__(self):
+        self.materials = []   # (albedo3, metal, smooth, emission3)
+        self.spheres = []     # (center3, radius, material)
+        self.rects = []       # (x1, x2, y1, y2, k, material)
+        self.meshes = []      # (pos9 (n,9), nrm9 (n,9), material, flip, blend)
+        self.lights = []      # (position3, brightness, color3 or None)
+        self.camera = ((0, 0, 0), (0, 0, -1), 60.0)
+
+    # -- oracle side ---------------------------------------------------------------------------
+    def oracle_scene(self):
+        mats = [orc.material(a, m, s, e) for a, m, s, e in self.materials]
+        spheres = [orc.Sphere(orc.f3(c), float(r), int(mi)) for c, r, mi in self.spheres]
+        rects = [orc.Rect(*[float(v) for v in r[:5]], int(r[5])) for r in self.rects]
+        tris = None
+        if self.meshes:
+            tris = np.concatenate([orc.tris_from_arrays(p, n, mi, fl, bl) for p, n, mi, fl, bl in self.meshes])
+        lights = [orc.point_light(p, b, c) for p, b, c in self.lights]
+        return orc.Scene(mats, spheres=spheres, rects=rects, tris=tris, lights=lights)
+
+    def oracle_camera(self, width, height):
+        o, l, fov = self.camera
+        return orc.camera(o, l, fov, float(np.float32(width) / np.float32(height)))
+
+    # -- host mirror side ------------------------------------------------------------------------
+    def host(self, width, height):
+        mats = [srt.Material(a, m, s, e) for a, m, s, e in self.materials]
+        world = srt.SurfaceList()
+        for p, n, mi, fl, bl in self.meshes:
+            world.surfaces.append(srt.TriMesh(p, n, mats[mi], fl, bl))
+        for c, r, mi in self.spheres:
+            world.surfaces.append(srt.Sphere(c, r, mats[mi]))
+        for r in self.rects:
+            world.surfaces.append(srt.RectAxis(r[0], r[1], r[2], r[3], r[4], mats[r[5]]))
+        world.Init()
+        lights = srt.LightList()
+        for p, b, c in self.lights:
+            lights.lights.append(srt.PointLight(p, b, c))
+        lights.init()
+        o, l, fov = self.camera
+        cam = srt.Camera(o, l, fov, game1.aspect_ratio(width, height))
+        return world, lights, cam
+
+
+def default_spec(with_rect=False):
+    """Game1.Initialize (Game1.cs:96-144)."""
+    s = SceneSpec()
+    z = (0, 0, 0)
+    s.materials = [((0.78, 0.79, 0.33), 0.0, 0.995, z), ((1.0, 0.65, 0.62), 1.0, 0.65, z), ((0.5, 0.425, 0.15), 0.0, 0.45, z),
+                   (z, 0, 0.0, (50.0, 0.5, 0.5)), (z, 0, 0.0, (0.5, 0.5, 50.0)), ((1.0, 0.5, 0.5), 0.0, 0.85, z)]
+    s.spheres = [((2.05, 0.9, -7.25), 3.5, 0), ((-4.5, 2.0, -8.0), 2.3, 1), ((0, 45, -20.0), 42.5, 2), ((-20, 0, 0.0), 2, 3),
+                 ((-15, 0, 6.0), 6, 4)]
+    if with_rect:
+        s.rects = [(-6, -3, -4, 4, -20, 3)]
+    s.lights = [((6.0, 2.0, 3.0), 5.0, None), ((0.0, 0.0, -12.0), 2.5, None)]
+    s.camera = ((0, 0, 0), (-0.03, 0.875, -7.6), 63)
+    return s
+
+
+# -- procedural meshes ---------------------------------------------------------------------------
+def uv_sphere(center, radius, n_lat, n_lon):
+    """Triangle soup of a latitude/longitude sphere with outward vertex normals -> (pos9, nrm9)."""
+    c = np.asarray(center, dtype=np.float64)
+    th = np.linspace(0, np.pi, n_lat + 1)
+    ph = np.linspace(0, 2 * np.pi, n_lon + 1)
+    T, P = np.meshgrid(th, ph, indexing="ij")
+    N = np.stack([np.sin(T) * np.cos(P), np.cos(T), np.sin(T) * np.sin(P)], axis=-1)
+    V = c + radius * N
+    pos, nrm = [], []
+    for i in range(n_lat):
+        for j in range(n_lon):
+            a, b, cc, d = (i, j), (i + 1, j), (i + 1, j + 1), (i, j + 1)
+            for tri in ((a, d, cc), (a, cc, b)):  # counter-clockwise seen from outside
+                p = [V[t] for t in tri]
+                if np.linalg.norm(np.cross(p[1] - p[0], p[2] - p[0])) < 1e-12:
+                    continue
+                pos.append(np.concatenate(p))
+                nrm.append(np.concatenate([N[t] for t in tri]))
+    return np.array(pos, dtype=np.float32), np.array(nrm, dtype=np.float32)
+
+
+def grid_plane(y, x0, x1, z0, z1, nx, nz, up=True):
+    """Axis-aligned flat grid (zero-thickness bounding boxes) at height y -> (pos9, nrm9)."""
+    xs = np.linspace(x0, x1, nx + 1)
+    zs = np.linspace(z0, z1, nz + 1)
+    pos, nrm = [], []
+    n = np.array([0, 1 if up else -1, 0], dtype=np.float64)
+    for i in range(nx):
+        for j in range(nz):
+            a = np.array([xs[i], y, zs[j]]); b = np.array([xs[i + 1], y, zs[j]])
+            c = np.array([xs[i + 1], y, zs[j + 1]]); d = np.array([xs[i], y, zs[j + 1]])
+            tris = ((a, c, b), (a, d, c)) if up else ((a, b, c), (a, c, d))
+            for tri in tris:
+                pos.append(np.concatenate(tri))
+                nrm.append(np.concatenate([n, n, n]))
+    return np.array(pos, dtype=np.float32), np.array(nrm, dtype=np.float32)
+
+
+def subdivide(pos9, nrm9, levels=1):
+    """Midpoint subdivision (x4 triangles per level); normals interpolated and re-normalised."""
+    p = np.asarray(pos9, dtype=np.float32).reshape(-1, 3, 3)
+    n = np.asarray(nrm9, dtype=np.float32).reshape(-1, 3, 3)
+    for _ in range(levels):
+        def mid(a, b):
+            return ((a.astype(np.float64) + b.astype(np.float64)) * 0.5).astype(np.float32)
+
+        def nmid(a, b):
+            m = a.astype(np.float64) + b.astype(np.float64)
+            l = np.linalg.norm(m, axis=-1, keepdims=True)
+            l[l == 0] = 1
+            return (m / l).astype(np.float32)
+        pa, pb, pc = p[:, 0], p[:, 1], p[:, 2]
+        na, nb, nc = n[:, 0], n[:, 1], n[:, 2]
+        pab, pbc, pca = mid(pa, pb), mid(pb, pc), mid(pc, pa)
+        nab, nbc, nca = nmid(na, nb), nmid(nb, nc), nmid(nc, na)
+        p = np.concatenate([np.stack(t, axis=1) for t in ((pa, pab, pca), (pab, pb, pbc), (pca, pbc, pc), (pab, pbc, pca))])
+        n = np.concatenate([np.stack(t, axis=1) for t in ((na, nab, nca), (nab, nb, nbc), (nca, nbc, nc), (nab, nbc, nca))])
+    return p.reshape(-1, 9), n.reshape(-1, 9)
+
+
+def mesh_spec(kind="sphere", n=16, with_spheres=True, with_rect=False):
+    """A small mixed scene: a triangle mesh + a ground grid + a few spheres, two lights."""
+    s = SceneSpec()
+    z = (0, 0, 0)
+    s.materials = [((1.0, 0.5, 0.5), 0.0, 0.85, z), ((0.6, 0.7, 0.9), 0.4, 0.7, z), ((0.5, 0.45, 0.3), 0.0, 0.3, z),
+                   ((0.9, 0.9, 0.9), 1.0, 0.9, z), (z, 0.0, 0.0, (4.0, 3.0, 1.0))]
+    if kind == "sphere":
+        p, nr = uv_sphere((0.2, 0.1, -6.0), 1.6, n, 2 * n)
+    else:
+        raise ValueError(kind)
+    s.meshes.append((p, nr, 0, False, True))
+    gp, gn = grid_plane(1.9, -6, 6, -12, -1, 6, 6, up=False)  # the image is y-down: the "floor" faces -y
+    s.meshes.append((gp, gn, 2, False, False))
+    if with_spheres:
+        s.spheres = [((-2.6, 0.6, -5.5), 1.0, 1), ((2.7, 0.9, -5.0), 0.8, 3), ((0.0, -3.0, -9.0), 0.7, 4)]
+    if with_rect:
+        s.rects = [(-3, 3, -3, 1, 9.0, 1)]  # RectAxis evaluates t = -k - o.z/d.z: with o.z = 0 the plane sits at z = -9 for d.z = -1 rays
+    s.lights = [((4.0, -3.0, 1.0), 5.0, None), ((-3.0, -2.0, -2.0), 2.0, (1.2, 0.4, 0.4))]
+    s.camera = ((0, 0, 0), (0.0, 0.2, -6.0), 55)
+    return s
+
+
+def max_lsb_diff(a, b):
+    """Largest per-channel difference between two packed RGBA images, and the number of differing pixels."""
+    da = orc.rgba_to_rgb8(np.asarray(a)).astype(np.int32)
+    db = orc.rgba_to_rgb8(np.asarray(b)).astype(np.int32)
+    d = np.abs(da - db)
+    return int(d.max()) if d.size else 0, int((d.max(axis=-1) > 0).sum()) if d.size else 0
+
+
+def psnr(a, b):
+    da = orc.rgba_to_rgb8(np.asarray(a)).astype(np.float64)
+    db = orc.rgba_to_rgb8(np.asarray(b)).astype(np.float64)
+    mse = np.mean((da - db) ** 2)
+    return float("inf") if mse == 0 else 10.0 * np.log10(255.0 ** 2 / mse)

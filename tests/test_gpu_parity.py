@@ -1,0 +1,159 @@
+"""GPU parity tests: libsrt.so on a real MI355X, called through its C ABI, against the CPU oracle and the committed
+golden fixtures.  Nothing here reads the reference tree."""
+import os
+
+import numpy as np
+import pytest
+
+import helpers
+import parity_cases
+import simple_raytracer_amd as srt
+from golden.make_golden import GOLDEN
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def gpu(gpu_renderer_factory):
+    r = gpu_renderer_factory()
+    yield r
+    r.close()
+
+
+@pytest.mark.parametrize("case", parity_cases.CASES, ids=[c[0] for c in parity_cases.CASES])
+def test_gpu_matches_oracle(gpu, oracle, case):
+    lsb, npx = parity_cases.assert_case(gpu, oracle, case)   # asserts <= 1 LSB and identical ray counts
+    print("%s: max %d LSB, %d differing pixels" % (case[0], lsb, npx))
+
+
+@pytest.mark.parametrize("name", sorted(GOLDEN))
+def test_gpu_reproduces_golden(gpu, name):
+    g = np.load(os.path.join(helpers.GOLDEN, name + ".npz"))
+    factory, kwargs, w, h, spp, depth, mode, kind, seed = GOLDEN[name]
+    world, lights, cam = getattr(helpers, factory)(**kwargs).host(w, h)
+    gpu.set_scene(world, lights, cam, world_kind=kind)
+    img = gpu.render(w, h, samples=spp, max_depth=depth, seed=seed, mode=mode)
+    lsb, npx = helpers.max_lsb_diff(img, g["image"])
+    assert lsb <= 1, "%s: %d LSB over %d pixels" % (name, lsb, npx)
+    if mode == srt.MODE_COLOR:
+        st = gpu.stats()
+        assert [st["rays_path"], st["rays_shadow"], st["hit_nodes"]] == g["counts"].tolist()
+
+
+def test_gpu_tile_layout(gpu, oracle):
+    lsb, npx = parity_cases.tiles_roundtrip(gpu, oracle)
+    assert lsb <= 1
+
+
+def test_gpu_counted_kernel_agrees(gpu):
+    world, lights, cam = helpers.mesh_spec(n=10).host(128, 72)
+    gpu.set_scene(world, lights, cam, world_kind=srt.WORLD_SURFACELIST)
+    a = gpu.render(128, 72, samples=2, max_depth=6, seed=3)
+    sa = gpu.stats()
+    b = gpu.render(128, 72, samples=2, max_depth=6, seed=3, counted=True)
+    sb = gpu.stats()
+    assert (a == b).all()
+    assert sa["rays_path"] == sb["rays_path"] and sb["box_tests"] > 0 and sb["tri_tests"] > 0 and sb["sphere_tests"] > 0
+    assert sa["kernel_ms"] > 0
+
+
+def test_gpu_async_poll_wait(gpu):
+    world, lights, cam = helpers.default_spec().host(256, 144)
+    gpu.set_scene(world, lights, cam)
+    want = gpu.render(256, 144, samples=4, max_depth=4, seed=2)
+    p = gpu.params(256, 144, samples=4, max_depth=4, seed=2)
+    out = np.zeros(256 * 144, dtype=np.uint32)
+    gpu.render_async(p, out)
+    with pytest.raises(srt.SrtError):     # one render in flight per context
+        gpu.render_async(p, out)
+    polls = 0
+    while not gpu.poll():
+        polls += 1
+        assert polls < 10_000_000
+    assert (out.reshape(144, 256) == want).all()
+    gpu.render_async(p, out)
+    gpu.wait()
+    assert (out.reshape(144, 256) == want).all()
+
+
+def test_gpu_error_behaviour(gpu_renderer_factory):
+    r = gpu_renderer_factory()
+    with pytest.raises(srt.SrtError) as e:
+        r.render(16, 16)                                   # nothing committed
+    assert e.value.code == srt._native.E_STATE
+    world, lights, cam = helpers.default_spec(with_rect=True).host(64, 36)
+    with pytest.raises(srt.SrtError) as e:
+        r.set_scene(world, lights, cam, world_kind=srt.WORLD_BVHNODE)   # the reference's BVHNode ctor would throw
+    assert e.value.code == srt._native.E_REFERENCE
+    r.set_scene(world, lights, cam, world_kind=srt.WORLD_SURFACELIST)
+    with pytest.raises(srt.SrtError) as e:
+        r.render(16, 16, color_clamp=-1.0)
+    assert e.value.code == srt._native.E_REFERENCE
+    with pytest.raises(srt.SrtError) as e:
+        r.render(16, 16, max_depth=99)
+    assert e.value.code == srt._native.E_LIMIT
+    r.close()
+
+
+def test_gpu_device_render_and_assemble(gpu, oracle):
+    """srt_render_device + srt_assemble_tiles on torch-owned device memory and torch's current stream: the
+    single-process rehearsal of what each rank and rank 0 do in a multi-GPU job."""
+    import torch
+    w, h, spp, world_size, tw, th = 200, 120, 2, 4, 32, 16
+    spec = helpers.default_spec()
+    world, lights, cam = spec.host(w, h)
+    gpu.set_scene(world, lights, cam)
+    ref, _ = spec.oracle_scene().render(spec.oracle_camera(w, h), w, h, samples=spp, max_depth=4, seed=6)
+    stream = torch.cuda.current_stream().cuda_stream
+    params = [gpu.params(w, h, samples=spp, max_depth=4, seed=6, layout=srt.LAYOUT_TILES, tile_w=tw, tile_h=th, rank=r,
+                         world_size=world_size) for r in range(world_size)]
+    stride = max(gpu.local_pixels(p) for p in params)
+    gathered = torch.zeros(world_size * stride, dtype=torch.int32, device="cuda")
+    for r, p in enumerate(params):
+        gpu.render_device(p, gathered.data_ptr() + 4 * r * stride, stride, stream)
+    frame = torch.zeros(h * w, dtype=torch.int32, device="cuda")
+    gpu.assemble_tiles(params[0], gathered.data_ptr(), stride, frame.data_ptr(), stream)
+    torch.cuda.synchronize()
+    img = frame.cpu().numpy().view(np.uint32).reshape(h, w)
+    lsb, npx = helpers.max_lsb_diff(img, ref)
+    assert lsb <= 1, (lsb, npx)
+
+
+# ---- BASELINE sizes: properties that need no full-size oracle render ---------------------------------------------------
+FULL = dict(width=1920, height=1080, samples=16, max_depth=8)   # BASELINE config 2
+
+
+def test_gpu_full_size_window_parity_and_invariants(gpu, oracle):
+    """1920x1080, 16 spp, depth 8 (the bench workload): (a) two renders are identical, (b) a 2-rank tile partition
+    gives the same pixels as the single frame, (c) an oracle render of a 96x54 window of the SAME full-size frame
+    matches the GPU's pixels there, (d) ray counts are reproducible."""
+    spec = helpers.default_spec()
+    w, h = FULL["width"], FULL["height"]
+    world, lights, cam = spec.host(w, h)
+    gpu.set_scene(world, lights, cam)
+    a = gpu.render(w, h, samples=16, max_depth=8, seed=1)
+    sa = gpu.stats()
+    b = gpu.render(w, h, samples=16, max_depth=8, seed=1)
+    sb = gpu.stats()
+    assert (a == b).all() and sa["rays_path"] == sb["rays_path"] and sa["rays_shadow"] == sb["rays_shadow"]
+    assert sa["rays_path"] > w * h * 16          # at least the primary rays
+    # (b) tiles of two ranks cover the frame with the same pixels
+    tw = th = 64
+    tiles_x, tiles_y = (w + tw - 1) // tw, (h + th - 1) // th
+    frame = np.zeros((h, w), dtype=np.uint32)
+    total_rays = 0
+    for rank in range(2):
+        buf = gpu.render(w, h, samples=16, max_depth=8, seed=1, layout=srt.LAYOUT_TILES, tile_w=tw, tile_h=th, rank=rank, world_size=2)
+        total_rays += gpu.stats()["rays_path"]
+        for j, t in enumerate(range(rank, tiles_x * tiles_y, 2)):
+            ty, tx = divmod(t, tiles_x)
+            y0, x0 = ty * th, tx * tw
+            hh, ww = min(th, h - y0), min(tw, w - x0)
+            frame[y0:y0 + hh, x0:x0 + ww] = buf[j * tw * th:(j + 1) * tw * th].reshape(th, tw)[:hh, :ww]
+    assert (frame == a).all() and total_rays == sa["rays_path"]
+    # (c) oracle on a window of the full-size frame (sphere edge, highlight and ground in view)
+    win = (1100, 560, 1196, 614)
+    ref, _ = spec.oracle_scene().render(spec.oracle_camera(w, h), w, h, samples=16, max_depth=8, seed=1, window=win)
+    x0, y0, x1, y1 = win
+    lsb, npx = helpers.max_lsb_diff(a[y0:y1, x0:x1], ref[y0:y1, x0:x1])
+    assert lsb <= 1, (lsb, npx)

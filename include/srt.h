@@ -148,9 +148,10 @@ int  srt_commit_scene(srt_ctx* ctx, int world_kind);
  * sized for the layout: width*height pixels for SRT_LAYOUT_FRAME, srt_local_pixels() for SRT_LAYOUT_TILES.
  * All rows are rendered (the reference leaves the last height mod N rows black, Game1.cs:378). */
 int  srt_render(srt_ctx* ctx, const srt_render_params* p, uint32_t* rgba_out);
-/* Same, writing to device memory on the caller's HIP stream (hipStream_t passed as void*, NULL = the
- * context's own stream) without synchronising: the host side of a multi-GPU job keeps the tiles on the
- * device for the gather.  capacity_pixels is the size of d_rgba_out in pixels. */
+/* Same, writing to device memory on the caller's HIP stream (hipStream_t passed as void*; NULL is HIP's
+ * default stream) without synchronising: the host side of a multi-GPU job keeps the tiles on the device
+ * for the gather.  capacity_pixels is the size of d_rgba_out in pixels.  The counters of such launches
+ * accumulate until srt_get_stats is called. */
 int  srt_render_device(srt_ctx* ctx, const srt_render_params* p, void* d_rgba_out, size_t capacity_pixels, void* hip_stream);
 /* srt_render with the event counters of srt_stats filled (a separately compiled, slower kernel). */
 int  srt_render_counted(srt_ctx* ctx, const srt_render_params* p, uint32_t* rgba_out);
@@ -161,7 +162,8 @@ int  srt_render_async(srt_ctx* ctx, const srt_render_params* p, uint32_t* rgba_o
 int  srt_poll(srt_ctx* ctx, int* done);
 int  srt_wait(srt_ctx* ctx);
 
-/* Counters of the last finished render of this context. */
+/* Counters of the renders since the previous collection (a blocking render collects, so after srt_render
+ * these are that render's counters).  Waits for the most recent launch. */
 int  srt_get_stats(srt_ctx* ctx, srt_stats* out);
 
 /* Size in pixels of the buffer a rank renders into for these parameters (tile-major, padded tiles). */

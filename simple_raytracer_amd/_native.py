@@ -87,6 +87,13 @@ def load(path=None, strict=True):
     if not os.path.exists(path):
         raise ImportError("%s is missing: build it with `make -C simple_raytracer_amd/csrc` (hipcc, gfx950). "
                           "There is no CPU fallback." % path)
+    # One HIP runtime per process: PyTorch wheels bundle their own libamdhip64.so, and a process that loads the
+    # system copy first (through this library) and torch's copy later ends up with a torch that sees no GPU.
+    # Importing torch first makes both resolve to the same runtime.
+    try:
+        import torch  # noqa: F401
+    except ImportError:
+        pass
     lib = C.CDLL(path)
     for name, restype, argtypes in SYMBOLS:
         if not strict and not hasattr(lib, name):

@@ -280,8 +280,7 @@ int srt_render_counted(srt_ctx* c, const srt_render_params* p, uint32_t* rgba_ou
 int srt_render_device(srt_ctx* c, const srt_render_params* p, void* d_rgba_out, size_t capacity_pixels, void* hip_stream)
 {
     if (!c) return SRT_E_INVALID;
-    hipStream_t s = hip_stream ? (hipStream_t)hip_stream : c->stream;
-    return launch(c, p, (uint32_t*)d_rgba_out, capacity_pixels, s, false);
+    return launch(c, p, (uint32_t*)d_rgba_out, capacity_pixels, (hipStream_t)hip_stream, false);
 }
 
 int srt_render_async(srt_ctx* c, const srt_render_params* p, uint32_t* rgba_out)
@@ -363,7 +362,7 @@ int srt_assemble_tiles(srt_ctx* c, const srt_render_params* p, const void* d_gat
     worst.layout = SRT_LAYOUT_TILES;
     if ((int64_t)stride_pixels < output_pixels(&worst)) return fail(c, SRT_E_INVALID, "stride_pixels smaller than rank 0's tile buffer");
     SRT_HIP(c, hipSetDevice(c->device));
-    hipStream_t s = hip_stream ? (hipStream_t)hip_stream : c->stream;
+    hipStream_t s = (hipStream_t)hip_stream;
     hipError_t e = launch_assemble(ra, (const uint32_t*)d_gathered, stride_pixels, (uint32_t*)d_frame, s);
     if (e != hipSuccess) return hip_fail(c, e, "assemble kernel launch");
     return SRT_OK;

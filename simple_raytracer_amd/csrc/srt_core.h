@@ -37,14 +37,11 @@ SRT_HD f3 neg3(f3 a) { return mk3(-a.x, -a.y, -a.z); }
 SRT_HD f3 scale3(f3 a, float s) { return mk3(a.x * s, a.y * s, a.z * s); }
 SRT_HD f3 mul3(f3 a, f3 b) { return mk3(a.x * b.x, a.y * b.y, a.z * b.z); }
 
-SRT_HD float sqrt_rn(float v)
-{
-#if defined(__HIP_DEVICE_COMPILE__)
-    return __fsqrt_rn(v);
-#else
-    return sqrtf(v);
-#endif
-}
+// Correctly rounded square root.  On the device this must be the plain sqrt lowered under
+// -fhip-fp32-correctly-rounded-divide-sqrt: HIP's __fsqrt_rn() is the native (approximate)
+// v_sqrt_f32 unless OCML_BASIC_ROUNDED_OPERATIONS is defined, and differs from IEEE in ~40 %
+// of inputs by one ulp.
+SRT_HD float sqrt_rn(float v) { return __builtin_sqrtf(v); }
 SRT_HD float dot3(f3 a, f3 b) { return a.x * b.x + a.y * b.y + a.z * b.z; }
 SRT_HD float lensq3(f3 a) { return a.x * a.x + a.y * a.y + a.z * a.z; }
 SRT_HD f3 cross3(f3 a, f3 b)

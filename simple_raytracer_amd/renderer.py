@@ -102,9 +102,10 @@ class Renderer:
         return out
 
     def render_device(self, p, device_ptr, capacity_pixels, stream=None):
-        """Launches the render into device memory on `stream` (a hipStream_t as int) without synchronising."""
+        """Launches the render into device memory on `stream` (a hipStream_t as int; 0/None = HIP's default stream)
+        without synchronising."""
         self._check(self._lib.srt_render_device(self._ctx, C.byref(p), C.c_void_p(device_ptr), capacity_pixels,
-                                                C.c_void_p(stream) if stream else None))
+                                                C.c_void_p(stream or 0)))
 
     def render_async(self, p, out):
         self._check(self._lib.srt_render_async(self._ctx, C.byref(p), out.ctypes.data_as(C.c_void_p)))
@@ -119,7 +120,7 @@ class Renderer:
 
     def assemble_tiles(self, p, gathered_ptr, stride_pixels, frame_ptr, stream=None):
         self._check(self._lib.srt_assemble_tiles(self._ctx, C.byref(p), C.c_void_p(gathered_ptr), stride_pixels,
-                                                 C.c_void_p(frame_ptr), C.c_void_p(stream) if stream else None))
+                                                 C.c_void_p(frame_ptr), C.c_void_p(stream or 0)))
 
     def stats(self):
         st = N.Stats()

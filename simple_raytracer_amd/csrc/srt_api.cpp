@@ -5,6 +5,7 @@
 #include <hip/hip_runtime_api.h>
 
 #include <chrono>
+#include <cstdlib>
 #include <cstring>
 #include <string>
 
@@ -28,8 +29,13 @@ struct srt_ctx {
     uint32_t* d_out = nullptr;
     size_t out_capacity = 0;  // pixels
     unsigned long long* d_stats = nullptr;
+    uint32_t* d_counter = nullptr;        // work counter of the persistent trace kernel
+    float* d_samples = nullptr;           // per-(sample, pixel) colours of one pass, 12 bytes each
+    size_t samples_capacity = 0;          // bytes
+    float* d_running = nullptr;           // per-pixel running sums, only for renders that need several passes
+    size_t running_capacity = 0;          // bytes
+    uint64_t sample_budget = (uint64_t)2 << 30;  // bytes the sample buffer may take (SRT_SAMPLE_BUFFER_MB)
     bool stats_pending = false;
-    bool counted_pending = false;
     srt_stats stats{};
     // asynchronous render (srt_render_async / srt_poll / srt_wait)
     uint32_t* h_pinned = nullptr;
@@ -114,9 +120,44 @@ int launch(srt_ctx* c, const srt_render_params* p, uint32_t* d_out, size_t capac
     if ((size_t)need > capacity) return fail(c, SRT_E_INVALID, "output buffer too small for this layout");
     if (!d_out) return fail(c, SRT_E_INVALID, "output pointer is NULL");
     SRT_HIP(c, hipSetDevice(c->device));
+    // Samples per pass: as many as fit the sample buffer budget (12 bytes per pixel and sample) and the
+    // 2^31 work-item limit of one launch.
+    if (ra.n_work == 0u) return SRT_OK;
+    uint64_t per_sample = (uint64_t)ra.n_work * 12u;
+    uint64_t fit = c->sample_budget / per_sample;
+    uint64_t by_items = (((uint64_t)1 << 31) - 1) / ra.n_work;
+    uint64_t per_pass = fit < by_items ? fit : by_items;
+    if (per_pass < 1) per_pass = 1;
+    if (per_pass > (uint64_t)ra.samples) per_pass = (uint64_t)ra.samples;
+    if ((uint64_t)ra.n_work > (((uint64_t)1 << 31) - 1)) return fail(c, SRT_E_LIMIT, "more than 2^31 pixels per rank");
+    size_t need_samples = (size_t)(per_pass * per_sample);
+    if (need_samples > c->samples_capacity) {
+        // (re)allocation waits for work in flight; steady-state renders of one size never get here
+        SRT_HIP(c, hipDeviceSynchronize());
+        if (c->d_samples) hipFree(c->d_samples);
+        c->d_samples = nullptr; c->samples_capacity = 0;
+        SRT_HIP(c, hipMalloc((void**)&c->d_samples, need_samples));
+        c->samples_capacity = need_samples;
+    }
+    const bool multi_pass = per_pass < (uint64_t)ra.samples;
+    if (multi_pass && (size_t)per_sample > c->running_capacity) {
+        SRT_HIP(c, hipDeviceSynchronize());
+        if (c->d_running) hipFree(c->d_running);
+        c->d_running = nullptr; c->running_capacity = 0;
+        SRT_HIP(c, hipMalloc((void**)&c->d_running, (size_t)per_sample));
+        c->running_capacity = (size_t)per_sample;
+    }
     SRT_HIP(c, hipEventRecord(c->ev_begin, stream));
-    hipError_t e = launch_trace(scene_view(c), ra, c->world_kind == SRT_WORLD_BVHNODE, counted, d_out, c->d_stats, stream);
-    if (e != hipSuccess) return hip_fail(c, e, "trace kernel launch");
+    const SceneView view = scene_view(c);
+    for (uint32_t s0 = 0; s0 < (uint32_t)ra.samples; s0 += (uint32_t)per_pass) {
+        ra.sample_first = s0;
+        ra.sample_count = (uint32_t)ra.samples - s0 < (uint32_t)per_pass ? (uint32_t)ra.samples - s0 : (uint32_t)per_pass;
+        ra.n_items = ra.n_work * ra.sample_count;
+        hipError_t e = launch_trace(view, ra, c->world_kind == SRT_WORLD_BVHNODE, counted, c->d_samples, c->d_stats, c->d_counter, stream);
+        if (e != hipSuccess) return hip_fail(c, e, "trace kernel launch");
+        e = launch_resolve(ra, c->d_samples, c->d_running, d_out, s0 == 0, s0 + ra.sample_count >= (uint32_t)ra.samples, stream);
+        if (e != hipSuccess) return hip_fail(c, e, "resolve kernel launch");
+    }
     SRT_HIP(c, hipEventRecord(c->ev_end, stream));
     c->stats_pending = true;
     return SRT_OK;
@@ -178,10 +219,15 @@ int srt_create(const srt_config* cfg, srt_ctx** out)
     bool ok = hipSetDevice(device) == hipSuccess && hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) == hipSuccess &&
               hipEventCreate(&c->ev_begin) == hipSuccess && hipEventCreate(&c->ev_end) == hipSuccess &&
               hipMalloc((void**)&c->d_stats, 8 * sizeof(unsigned long long)) == hipSuccess &&
+              hipMalloc((void**)&c->d_counter, sizeof(uint32_t)) == hipSuccess &&
               hipMemset(c->d_stats, 0, 8 * sizeof(unsigned long long)) == hipSuccess && hipDeviceSynchronize() == hipSuccess;
     if (!ok) {
         srt_destroy(c);
         return fail(nullptr, SRT_E_HIP, "could not create stream / events / counters on the device");
+    }
+    if (const char* mb = std::getenv("SRT_SAMPLE_BUFFER_MB")) {
+        long v = std::atol(mb);
+        if (v > 0) c->sample_budget = (uint64_t)v << 20;
     }
     *out = c;
     return SRT_OK;
@@ -195,6 +241,9 @@ void srt_destroy(srt_ctx* c)
     free_scene_buffers(c);
     if (c->d_out) hipFree(c->d_out);
     if (c->d_stats) hipFree(c->d_stats);
+    if (c->d_counter) hipFree(c->d_counter);
+    if (c->d_samples) hipFree(c->d_samples);
+    if (c->d_running) hipFree(c->d_running);
     if (c->h_pinned) hipHostFree(c->h_pinned);
     if (c->ev_begin) hipEventDestroy(c->ev_begin);
     if (c->ev_end) hipEventDestroy(c->ev_end);

@@ -533,7 +533,10 @@ struct RenderArgs {
     int32_t mode, layout;
     int32_t tile_w, tile_h, rank, world_size;
     int32_t tiles_x, tiles_y;       // tile grid of the full image
-    uint32_t n_work;                // pixels (incl. padding of edge tiles) owned by this rank
+    uint32_t n_work;                // pixels (incl. padding of edge tiles) owned by this rank; a multiple of 64
+    // one pass of the trace kernel covers samples [sample_first, sample_first + sample_count) of every pixel
+    uint32_t sample_first, sample_count;
+    uint32_t n_items;               // n_work * sample_count work items (one per pixel and sample)
 };
 
 // A parent waiting for its children (one per pending level of the recursion).

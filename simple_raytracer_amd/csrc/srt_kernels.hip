@@ -1,61 +1,109 @@
-// srt_kernels.hip -- gfx950 kernels: the trace megakernel and the tile assembly kernel.
+// srt_kernels.hip -- gfx950 kernels: the persistent trace kernel, the sample resolve kernel and
+// the tile assembly kernel.
 //
-// One lane owns one pixel at a time.  A lane is a small state machine (srt_core.h, advance())
-// that always has exactly one ray query pending -- the closest-hit query of a ray-tree node
-// or the shadow query of one of its lights -- so the 64 lanes of a wavefront run the BVH
-// traversal loop together whatever stage of their ray trees they are in.  The traversal
-// stack is a per-wavefront slab of LDS with one column per lane (entry i of lane l at
-// [i][l]: conflict-free), the ray-tree frames (one per pending recursion level) are private.
+// trace_kernel.  Work items are (pixel, sample) pairs.  Wavefronts are persistent: each one
+// draws chunks of items from a global counter (one atomic per chunk) and deals them to its
+// idle lanes with a ballot + prefix count, so lanes whose ray tree ended are refilled at once
+// instead of idling until the slowest lane of the wavefront is done.  A lane is a small state
+// machine (srt_path.h): it is either waiting for the closest-hit query of a tree node (TRACE)
+// or owes the shadow queries and the shading of a node that was hit (LIGHT).  Each trip of the
+// main loop the wavefront votes for one of the two code sections and every lane in that phase
+// executes it together; lanes in the other phase wait.  That keeps the 64 lanes on the same
+// instructions instead of serialising the sections under divergent masks.
+// The BVH traversal stack is a per-wavefront slab of LDS with one column per lane (entry i of
+// lane l at [i][l]: conflict-free); the ray-tree frames (one per pending recursion level) are
+// private memory.
 #include <hip/hip_runtime.h>
 
-#include "srt_core.h"
 #include "srt_launch.h"
+#include "srt_path.h"
 
 namespace srt {
 
 constexpr int kBlock = 256;
 constexpr int kWaves = kBlock / 64;
+constexpr uint32_t kChunk = 256;       // items drawn from the global counter at a time
+constexpr int kTraceVote = 24;         // run the TRACE section while at least this many lanes want it
+constexpr int kMaxBlocks = 256 * 8;    // persistent grid: never more blocks than 8 per CU
 
 __device__ __forceinline__ unsigned long long wave_sum(unsigned long long v)
 {
     for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
     return v;
 }
+__device__ __forceinline__ uint32_t lanes_below(unsigned long long mask)
+{
+    return __builtin_amdgcn_mbcnt_hi((uint32_t)(mask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mask, 0u));
+}
 
 template <bool EXACT, bool COUNT>
-__global__ void __launch_bounds__(kBlock) trace_kernel(SceneView sc, RenderArgs ra, uint32_t* __restrict__ out, unsigned long long* __restrict__ stats)
+__global__ void __launch_bounds__(kBlock) trace_kernel(SceneView sc, RenderArgs ra, f3* __restrict__ samples,
+                                                       unsigned long long* __restrict__ stats, uint32_t* __restrict__ work_counter)
 {
     __shared__ uint32_t lds_stack[kWaves][STACK_DEPTH][64];
     const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
     uint32_t* my_stack = &lds_stack[wave][0][lane];
 
-    PathState st;
+    Lane ln;
     Frame frames[FRAME_SLOTS];
     Counters cnt;
     cnt.box_tests = cnt.sphere_tests = cnt.tri_tests = cnt.rect_tests = 0u;
-    st.rays_path = st.rays_shadow = st.hit_nodes = 0u;
+    ln.rays_path = ln.rays_shadow = ln.hit_nodes = 0u;
+    int phase = LANE_IDLE;
 
-    const uint32_t work = blockIdx.x * (uint32_t)kBlock + threadIdx.x;
-    bool alive = false;
-    if (work < ra.n_work) {
-        int32_t x, y;
-        uint32_t oi;
-        if (work_to_pixel(ra, work, x, y, oi)) {
-            start_pixel(st, ra, oi, x, y);
-            alive = true;
-        } else if (ra.layout != 0) {
-            out[oi] = 0u;  // padding pixel of an edge tile
+    uint32_t next = 0u, end = 0u;  // wave-uniform: the wavefront's private range of items
+    bool dry = false;              // wave-uniform: the global counter is exhausted
+
+    for (;;) {
+        // ---- deal items to idle lanes
+        unsigned long long idle = __ballot(phase == LANE_IDLE);
+        while (idle != 0ull) {
+            if (next >= end) {
+                if (dry) break;
+                uint32_t base = 0u;
+                if (lane == 0u) base = atomicAdd(work_counter, kChunk);
+                base = __builtin_amdgcn_readfirstlane(base);
+                if (base >= ra.n_items) { dry = true; break; }
+                next = base;
+                end = base + kChunk < ra.n_items ? base + kChunk : ra.n_items;
+            }
+            uint32_t avail = end - next, want = (uint32_t)__popcll(idle);
+            uint32_t rank = lanes_below(idle);
+            if (phase == LANE_IDLE && rank < avail) {
+                if (item_start(ln, ra, next + rank)) phase = LANE_TRACE;  // padding pixels of edge tiles are skipped
+            }
+            next += want < avail ? want : avail;
+            idle = __ballot(phase == LANE_IDLE);
+        }
+        const int n_trace = __popcll(__ballot(phase == LANE_TRACE));
+        const int n_light = __popcll(__ballot(phase == LANE_LIGHT));
+        if (n_trace + n_light == 0) break;
+
+        if (n_trace >= kTraceVote || n_light == 0) {
+            // ---- TRACE section: closest-hit query of a tree node
+            if (phase == LANE_TRACE) {
+                Hit h = closest_hit<EXACT, COUNT, 64>(sc, ln.qo, ln.qd, ln.qtmin, my_stack, cnt);
+                f3 ret;
+                phase = lane_on_closest(ln, h, ret, sc, ra, frames);
+                if (phase == LANE_IDLE) samples[ln.slot] = ret;
+            }
+        } else {
+            // ---- LIGHT section: one shadow query per light, then the node's shading
+            if (phase == LANE_LIGHT) {
+                for (uint32_t li = 0; li < sc.n_lights; li++) {
+                    f3 o, d;
+                    lane_shadow_query(ln, sc, li, o, d);
+                    Hit h = closest_hit<EXACT, COUNT, 64>(sc, o, d, 0.001f, my_stack, cnt);
+                    lane_on_shadow(ln, h, o, d, sc, li);
+                }
+                f3 ret;
+                phase = lane_shade(ln, ln.former, ret, sc, ra, frames);
+                if (phase == LANE_IDLE) samples[ln.slot] = ret;
+            }
         }
     }
-    while (alive) {
-        Hit h = closest_hit<EXACT, COUNT, 64>(sc, st.qo, st.qd, st.qtmin, my_stack, cnt);
-        if (advance(st, h, sc, ra, frames)) {
-            out[st.work] = finish_pixel(st);
-            alive = false;
-        }
-    }
 
-    unsigned long long v0 = wave_sum(st.rays_path), v1 = wave_sum(st.rays_shadow), v2 = wave_sum(st.hit_nodes);
+    unsigned long long v0 = wave_sum(ln.rays_path), v1 = wave_sum(ln.rays_shadow), v2 = wave_sum(ln.hit_nodes);
     if (lane == 0u) {
         atomicAdd(&stats[0], v0);
         atomicAdd(&stats[1], v1);
@@ -70,6 +118,25 @@ __global__ void __launch_bounds__(kBlock) trace_kernel(SceneView sc, RenderArgs 
             atomicAdd(&stats[6], c3);
         }
     }
+}
+
+// One thread per pixel of this rank: adds the pass's samples in index order to the running sum
+// (Game1.cs:295) and, after the last pass, applies gamma and packs (Game1.cs:301-306).
+__global__ void __launch_bounds__(kBlock) resolve_kernel(RenderArgs ra, const f3* __restrict__ samples, f3* __restrict__ running,
+                                                         uint32_t* __restrict__ out, int first_pass, int last_pass)
+{
+    uint32_t wp = blockIdx.x * (uint32_t)kBlock + threadIdx.x;
+    if (wp >= ra.n_work) return;
+    int32_t x, y;
+    uint32_t oi;
+    if (!work_to_pixel(ra, wp, x, y, oi)) {
+        if (ra.layout != 0 && last_pass) out[oi] = 0u;  // padding pixel of an edge tile
+        return;
+    }
+    f3 acc = first_pass ? mk3(0.0f, 0.0f, 0.0f) : running[wp];
+    acc = accumulate_samples(acc, samples, ra.n_work, wp, ra.sample_count, 1.0f / (float)ra.samples);
+    if (last_pass) out[oi] = finish_color(acc);
+    else running[wp] = acc;
 }
 
 // Rank 0 of a multi-GPU job: pixel (x, y) of the frame lives in tile t = tx + ty*tiles_x, which
@@ -87,17 +154,33 @@ __global__ void __launch_bounds__(kBlock) assemble_kernel(RenderArgs ra, const u
     frame[i] = gathered[(size_t)r * stride + (size_t)j * (uint32_t)(ra.tile_w * ra.tile_h) + ly * (uint32_t)ra.tile_w + lx];
 }
 
-hipError_t launch_trace(const SceneView& sc, const RenderArgs& ra, bool exact, bool counted, uint32_t* d_out, unsigned long long* d_stats, hipStream_t stream)
+hipError_t launch_trace(const SceneView& sc, const RenderArgs& ra, bool exact, bool counted, float* d_samples,
+                        unsigned long long* d_stats, uint32_t* d_work_counter, hipStream_t stream)
+{
+    if (ra.n_items == 0u) return hipSuccess;
+    hipError_t e = hipMemsetAsync(d_work_counter, 0, sizeof(uint32_t), stream);
+    if (e != hipSuccess) return e;
+    uint32_t blocks = (ra.n_items + kBlock - 1) / kBlock;
+    if (blocks > (uint32_t)kMaxBlocks) blocks = kMaxBlocks;
+    dim3 grid(blocks), block(kBlock);
+    f3* s = reinterpret_cast<f3*>(d_samples);
+    if (exact) {
+        if (counted) hipLaunchKernelGGL((trace_kernel<true, true>), grid, block, 0, stream, sc, ra, s, d_stats, d_work_counter);
+        else hipLaunchKernelGGL((trace_kernel<true, false>), grid, block, 0, stream, sc, ra, s, d_stats, d_work_counter);
+    } else {
+        if (counted) hipLaunchKernelGGL((trace_kernel<false, true>), grid, block, 0, stream, sc, ra, s, d_stats, d_work_counter);
+        else hipLaunchKernelGGL((trace_kernel<false, false>), grid, block, 0, stream, sc, ra, s, d_stats, d_work_counter);
+    }
+    return hipGetLastError();
+}
+
+hipError_t launch_resolve(const RenderArgs& ra, const float* d_samples, float* d_running, uint32_t* d_out, bool first_pass, bool last_pass,
+                          hipStream_t stream)
 {
     if (ra.n_work == 0u) return hipSuccess;
     dim3 grid((ra.n_work + kBlock - 1) / kBlock), block(kBlock);
-    if (exact) {
-        if (counted) hipLaunchKernelGGL((trace_kernel<true, true>), grid, block, 0, stream, sc, ra, d_out, d_stats);
-        else hipLaunchKernelGGL((trace_kernel<true, false>), grid, block, 0, stream, sc, ra, d_out, d_stats);
-    } else {
-        if (counted) hipLaunchKernelGGL((trace_kernel<false, true>), grid, block, 0, stream, sc, ra, d_out, d_stats);
-        else hipLaunchKernelGGL((trace_kernel<false, false>), grid, block, 0, stream, sc, ra, d_out, d_stats);
-    }
+    hipLaunchKernelGGL(resolve_kernel, grid, block, 0, stream, ra, reinterpret_cast<const f3*>(d_samples), reinterpret_cast<f3*>(d_running),
+                       d_out, first_pass ? 1 : 0, last_pass ? 1 : 0);
     return hipGetLastError();
 }
 

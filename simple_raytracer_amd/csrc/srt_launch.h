@@ -8,10 +8,16 @@
 
 namespace srt {
 
-// stats: 8 x uint64 on the device: rays_path, rays_shadow, hit_nodes, box_tests, sphere_tests,
-// tri_tests, rect_tests, (unused).  The kernel adds to them; the caller zeroes them.
-hipError_t launch_trace(const SceneView& sc, const RenderArgs& ra, bool exact, bool counted, uint32_t* d_out,
-                        unsigned long long* d_stats, hipStream_t stream);
+// One pass of the trace kernel over samples [ra.sample_first, ra.sample_first + ra.sample_count) of this
+// rank's pixels.  d_samples: 3 floats per (sample, pixel), sample-major, ra.sample_count * ra.n_work entries.
+// d_stats: 8 x uint64 the kernel adds to: rays_path, rays_shadow, hit_nodes, box_tests, sphere_tests,
+// tri_tests, rect_tests, (unused).  d_work_counter: one uint32, reset by the launcher on `stream`.
+hipError_t launch_trace(const SceneView& sc, const RenderArgs& ra, bool exact, bool counted, float* d_samples,
+                        unsigned long long* d_stats, uint32_t* d_work_counter, hipStream_t stream);
+// Adds the pass's samples to the per-pixel running sums (3 floats per pixel; untouched when the pass is both the
+// first and the last) and, on the last pass, writes the packed pixels.
+hipError_t launch_resolve(const RenderArgs& ra, const float* d_samples, float* d_running, uint32_t* d_out, bool first_pass, bool last_pass,
+                          hipStream_t stream);
 hipError_t launch_assemble(const RenderArgs& ra, const uint32_t* d_gathered, size_t stride, uint32_t* d_frame, hipStream_t stream);
 
 }  // namespace srt

@@ -1,0 +1,233 @@
+// srt_path.h -- the ray tree of one sample as a per-lane state machine.
+//
+// A work item is one (pixel, sample): the lane walks the sample's ray tree depth first
+// (RayOperations.GetRayColor, RaytracingOperations.cs:75-195) and leaves the sample's colour in
+// a sample buffer; a second kernel adds the samples of each pixel in index order, which is the
+// order Game1.cs:281-296 adds them in, so the float sum is the same.
+//
+// A lane is in one of two phases:
+//   TRACE  it holds the closest-hit query of a tree node (world.hit(ray, 0.01, inf, record));
+//   LIGHT  the node was hit: it still owes one shadow query per light (LightList.calculateLight,
+//          RaytracingClasses.cs:205-218) and then the node's shading, which either starts the
+//          first child (back to TRACE) or completes nodes up the tree.
+// The kernel runs the two phases as separate, wave-wide code sections, so that lanes which
+// execute a section all execute the same code.
+#ifndef SRT_PATH_H
+#define SRT_PATH_H
+
+#include "srt_core.h"
+
+namespace srt {
+
+enum { LANE_IDLE = 0, LANE_TRACE = 1, LANE_LIGHT = 2 };
+
+struct Lane {
+    uint32_t slot;      // where the sample's colour goes in the sample buffer
+    RngKey key;         // key.node = id of the tree node being evaluated
+    int32_t depth;      // `depth` argument of the current GetRayColor call
+    int32_t level;      // frames in use
+    f3 qo, qd;          // pending closest-hit query (TRACE) / the node's ray (LIGHT: qd is its direction)
+    float qtmin;
+    f3 P, N;            // hit being lit (LIGHT)
+    uint32_t mat;
+    f3 former;          // formerLightLevel
+    uint32_t rays_path, rays_shadow, hit_nodes;
+};
+
+// Work item -> (pixel, sample).  Items enumerate 64-pixel blocks (8x8 pixels of one tile), and inside
+// a block all samples of the pass, 64 pixels at a time, so that 64 consecutive items are one 8x8
+// pixel block at one sample index.  Returns false for padding pixels of edge tiles.
+SRT_HD bool item_start(Lane& ln, const RenderArgs& ra, uint32_t item)
+{
+    uint32_t per_block = 64u * ra.sample_count;
+    uint32_t blk = item / per_block, r = item - blk * per_block;
+    uint32_t s_local = r >> 6, k = r & 63u;
+    uint32_t wp = blk * 64u + k;
+    int32_t x, y;
+    uint32_t unused;
+    if (!work_to_pixel(ra, wp, x, y, unused)) return false;
+    ln.slot = s_local * ra.n_work + wp;
+    ln.key.seed = ra.seed;
+    ln.key.pixel = (uint32_t)x + (uint32_t)y * (uint32_t)ra.width;
+    ln.key.sample = ra.sample_first + s_local;
+    // Game1.cs:283-287: jittered viewport coordinates and the primary ray
+    ln.key.node = 0u;
+    uint32_t a, b, c, d;
+    rng_words(ln.key, SLOT_JITTER, a, b, c, d);
+    float u = ((float)x + (float)rng_next(a, -50, 50) / 100.0f) / (float)ra.width;
+    float v = ((float)y + (float)rng_next(b, -50, 50) / 100.0f) / (float)ra.height;
+    const Camera& cm = ra.cam;
+    f3 dir = mk3(((cm.lower_left.x + u * cm.horizontal.x) + v * cm.vertical.x) - cm.position.x,
+                 ((cm.lower_left.y + u * cm.horizontal.y) + v * cm.vertical.y) - cm.position.y,
+                 ((cm.lower_left.z + u * cm.horizontal.z) + v * cm.vertical.z) - cm.position.z);
+    ln.qo = cm.position;
+    ln.qd = normalize3(dir);
+    ln.qtmin = ((uint32_t)ra.mode == MODE_NORMAL || (uint32_t)ra.mode == MODE_DEPTH) ? 0.0f : 0.01f;
+    ln.key.node = 1u;
+    ln.depth = ra.max_depth;
+    ln.level = 0;
+    return true;
+}
+
+SRT_HD void lane_begin_child(Lane& ln, uint32_t child, f3 origin, f3 unit_dir, int32_t depth)
+{
+    ln.key.node = ln.key.node * 4u + child + 1u;
+    ln.qo = origin; ln.qd = unit_dir; ln.qtmin = 0.01f;
+    ln.depth = depth;
+}
+
+SRT_HD f3 clamp_color(f3 c, float hi) { return mk3(clampf(c.x, 0.0f, hi), clampf(c.y, 0.0f, hi), clampf(c.z, 0.0f, hi)); }
+
+// The GetRayColor call of node ln.key.node returned `ret`: hand it to the parent, start the next
+// child or complete parents up the tree.  Returns LANE_TRACE with a new query, or LANE_IDLE
+// with `ret` holding the colour of the whole sample.
+SRT_HD int lane_return(Lane& ln, f3& ret, const SceneView& sc, const RenderArgs& ra, Frame* frames)
+{
+    while (ln.level > 0) {
+        Frame& f = frames[ln.level - 1];
+        uint32_t mat = f.meta & 0x00FFFFFFu;
+        int32_t child_depth = (int32_t)(f.meta >> 24);
+        Material m = load_material(sc, mat);
+        uint32_t child = (ln.key.node & 3u) - 1u;  // which child just returned
+        ln.key.node >>= 2;                          // back to the parent's id
+        f3 acc = f.acc;
+        uint32_t next;
+        // RaytracingOperations.cs:156-183: emission + albedo(1-m) 0.7 C_diffuse + albedo m C_metal
+        //                                  + (1-m) fresnel s^2 C_reflect + lightColor, left to right
+        if (child == 0u) {
+            f3 wd = scale3(scale3(m.albedo, 1.0f - m.metalness), 0.7f);
+            acc = add3(acc, mul3(wd, ret));
+            next = (m.metalness != 0.0f) ? 1u : 2u;
+        } else if (child == 1u) {
+            acc = add3(acc, mul3(scale3(m.albedo, m.metalness), ret));
+            next = (m.metalness != 1.0f) ? 2u : 3u;
+        } else {
+            acc = add3(acc, scale3(ret, f.w_refl));
+            next = 3u;
+        }
+        if (next < 3u) {
+            f.acc = acc;
+            lane_begin_child(ln, next, f.point, f.refl, child_depth);
+            return LANE_TRACE;
+        }
+        ret = clamp_color(add3(acc, f.light), ra.color_clamp);  // :186-188, at every level
+        ln.level--;
+    }
+    return LANE_IDLE;
+}
+
+// All lights of the node are in (light_color = lightColor of RaytracingOperations.cs:144): directions of the
+// children, fresnel, and either the first child or -- when the children would run at depth < 1 -- the node's value.
+SRT_HD int lane_shade(Lane& ln, f3 light_color, f3& ret, const SceneView& sc, const RenderArgs& ra, Frame* frames)
+{
+    if ((uint32_t)ra.mode == MODE_LIGHTS) { ret = light_color; return LANE_IDLE; }
+    Material m = load_material(sc, ln.mat);
+    f3 hemi = random_hemisphere_vector(ln.key, ln.N);
+    f3 diffuse_dir = add3(ln.N, hemi);                                                  // :119
+    f3 rough = random_ranged_vector(ln.key, SLOT_REFLECT, sqrt_rn(m.smoothness));
+    f3 refl = reflect3(ln.qd, add3(ln.N, rough));                                       // :128
+    float fres = fresnel_term(ln.qd, refl);                                             // :137-140
+    float w_refl = (1.0f - m.metalness) * (fres * (m.smoothness * m.smoothness));
+    int32_t child_depth = ln.depth - 1;
+    if (child_depth < 1) {
+        // every child returns Vector3.Zero without tracing (:82-83)
+        f3 zero = mk3(0.0f, 0.0f, 0.0f);
+        f3 wd = scale3(scale3(m.albedo, 1.0f - m.metalness), 0.7f);
+        f3 acc = add3(m.emission, mul3(wd, zero));
+        if (m.metalness != 0.0f) acc = add3(acc, mul3(scale3(m.albedo, m.metalness), zero));
+        if (m.metalness != 1.0f) acc = add3(acc, scale3(zero, w_refl));
+        ret = clamp_color(add3(acc, light_color), ra.color_clamp);
+        return lane_return(ln, ret, sc, ra, frames);
+    }
+    Frame& f = frames[ln.level];
+    f.acc = m.emission;
+    f.light = light_color;
+    f.point = ln.P;
+    f.refl = normalize3(refl);  // CustomRay normalises; the metal and the reflect child share the direction
+    f.w_refl = w_refl;
+    f.meta = ln.mat | ((uint32_t)child_depth << 24);
+    ln.level++;
+    lane_begin_child(ln, 0u, ln.P, normalize3(diffuse_dir), child_depth);
+    return LANE_TRACE;
+}
+
+// TRACE phase: the closest-hit query came back.  Returns the lane's next phase; LANE_IDLE means the
+// sample is complete and `ret` is its colour.
+SRT_HD int lane_on_closest(Lane& ln, const Hit& h, f3& ret, const SceneView& sc, const RenderArgs& ra, Frame* frames)
+{
+    const uint32_t mode = (uint32_t)ra.mode;
+    if (mode == MODE_NORMAL || mode == MODE_DEPTH) {
+        // RaytracingOperations.cs:11-35; the miss branch normalises the direction once more
+        if (h.prim != NO_PRIM) {
+            HitRecord r = resolve_hit(sc, h, ln.qo, ln.qd);
+            if (mode == MODE_NORMAL) ret = mk3(0.5f * (r.normal.x + 1.0f), 0.5f * (r.normal.y + 1.0f), 0.5f * (r.normal.z + 1.0f));
+            else {
+                float value = sqrt_rn(distsq3(ln.qo, r.point));
+                float c = 1.0f - (0.07f * value);
+                ret = mk3(c, c, c);
+            }
+        } else {
+            f3 dn = normalize3(ln.qd);
+            float t = 0.5f * (dn.y + 1.0f);
+            if (mode == MODE_NORMAL) ret = mk3(t * 0.2f + (1.0f - t) * 0.5f, t * 0.2f + (1.0f - t) * 0.7f, t * 0.2f + (1.0f - t) * 1.0f);
+            else ret = mk3(t * 0.0f, t * 0.0f, t * 0.0f);
+        }
+        return LANE_IDLE;
+    }
+    if (mode == MODE_LIGHTS) {
+        // GetLights on the primary ray (RaytracingOperations.cs:197-205)
+        if (h.prim == NO_PRIM || sc.n_lights == 0u) { ret = mk3(0.0f, 0.0f, 0.0f); return LANE_IDLE; }
+    } else {
+        // :82-83: depth < 1 returns black before anything is traced (a primary ray with max_depth 0)
+        if (ln.depth < 1) { ret = mk3(0.0f, 0.0f, 0.0f); return lane_return(ln, ret, sc, ra, frames); }
+        ln.rays_path++;
+        if (h.prim == NO_PRIM) { ret = sky_color(ln.qd.y); return lane_return(ln, ret, sc, ra, frames); }
+        ln.hit_nodes++;
+    }
+    HitRecord r = resolve_hit(sc, h, ln.qo, ln.qd);
+    ln.P = r.point; ln.N = r.normal; ln.mat = r.material;
+    if (mode != MODE_LIGHTS) ln.depth = depth_heuristic(ln.depth, sc.materials[2 * r.material + 1].x);
+    ln.former = mk3(0.0f, 0.0f, 0.0f);
+    if (sc.n_lights == 0u) return lane_shade(ln, ln.former, ret, sc, ra, frames);
+    return LANE_LIGHT;
+}
+
+// LIGHT phase, light `li`: its shadow ray ...
+SRT_HD void lane_shadow_query(const Lane& ln, const SceneView& sc, uint32_t li, f3& o, f3& d)
+{
+    Light L = load_light(sc, li);
+    o = ln.P;
+    d = shadow_direction(L, ln.P, ln.key, li);
+}
+// ... and its contribution once the shadow ray (o, d) came back: formerLightLevel += calculateLight(formerLightLevel, ...)
+SRT_HD void lane_on_shadow(Lane& ln, const Hit& h, f3 o, f3 d, const SceneView& sc, uint32_t li)
+{
+    ln.rays_shadow++;
+    Material m = load_material(sc, ln.mat);
+    Light L = load_light(sc, li);
+    bool sh = h.prim != NO_PRIM;
+    f3 P_s = ln.P;
+    float metal_s = m.metalness;
+    if (sh) {
+        P_s = ray_at(o, d, h.t);
+        metal_s = sc.materials[2 * hit_material(sc, h)].w;
+    }
+    f3 c = point_light(L, ln.P, ln.N, ln.qd, m, ln.former, sh, h.t, P_s, metal_s);
+    ln.former = add3(ln.former, c);
+}
+
+// Adds the samples of one pass to a pixel in sample order (Game1.cs:295: vectorRayColor += c / samples,
+// Vector3 / float being a multiplication by 1/samples).
+SRT_HD f3 accumulate_samples(f3 acc, const f3* samples, uint32_t stride, uint32_t wp, uint32_t count, float inv)
+{
+    for (uint32_t s = 0; s < count; s++) {
+        f3 c = samples[(size_t)s * stride + wp];
+        acc = mk3(acc.x + c.x * inv, acc.y + c.y * inv, acc.z + c.z * inv);
+    }
+    return acc;
+}
+// Game1.cs:301-306: gamma (sqrt per channel) and packing.
+SRT_HD uint32_t finish_color(f3 acc) { return pack_color(sqrt_rn(acc.x), sqrt_rn(acc.y), sqrt_rn(acc.z)); }
+
+}  // namespace srt
+#endif  // SRT_PATH_H

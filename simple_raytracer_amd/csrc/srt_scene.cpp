@@ -471,6 +471,9 @@ int make_render_args(const srt_render_params* p, const Camera& cam, RenderArgs& 
     int64_t work = local_tiles(p, tw, th, world) * tw * th;
     if (work >= ((int64_t)1 << 32)) { err = "more than 2^32 work items"; return SRT_E_LIMIT; }
     ra.n_work = (uint32_t)work;
+    ra.sample_first = 0u;
+    ra.sample_count = (uint32_t)p->samples;
+    ra.n_items = 0u;  // set per pass by the launcher
     return SRT_OK;
 }
 

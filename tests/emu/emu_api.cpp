@@ -11,7 +11,9 @@
 #include <vector>
 
 #include "../../include/srt.h"
-#include "../../simple_raytracer_amd/csrc/srt_core.h"
+#include <algorithm>
+
+#include "../../simple_raytracer_amd/csrc/srt_path.h"
 #include "../../simple_raytracer_amd/csrc/srt_scene.h"
 
 using namespace srt;
@@ -31,28 +33,36 @@ namespace {
 
 struct Totals { uint64_t v[7] = {0, 0, 0, 0, 0, 0, 0}; };
 
+// Items [i0, i1) of one pass, one lane at a time: the same per-lane functions the kernel calls, without the
+// wavefront scheduling around them (which does not influence results).
 template <bool EXACT>
-void run_range(const SceneView& sc, const RenderArgs& ra, uint32_t w0, uint32_t w1, uint32_t* out, Totals* tot)
+void run_items(const SceneView& sc, const RenderArgs& ra, uint32_t i0, uint32_t i1, f3* samples, Totals* tot)
 {
     std::vector<uint32_t> stack(STACK_DEPTH);
     Counters cnt{0, 0, 0, 0};
-    for (uint32_t work = w0; work < w1; work++) {
-        int32_t x, y;
-        uint32_t oi;
-        if (!work_to_pixel(ra, work, x, y, oi)) {
-            if (ra.layout != 0) out[oi] = 0u;
-            continue;
-        }
-        PathState st;
+    for (uint32_t item = i0; item < i1; item++) {
+        Lane ln;
         Frame frames[FRAME_SLOTS];
-        st.rays_path = st.rays_shadow = st.hit_nodes = 0u;
-        start_pixel(st, ra, oi, x, y);
-        for (;;) {
-            Hit h = closest_hit<EXACT, true, 1>(sc, st.qo, st.qd, st.qtmin, stack.data(), cnt);
-            if (advance(st, h, sc, ra, frames)) break;
+        ln.rays_path = ln.rays_shadow = ln.hit_nodes = 0u;
+        if (!item_start(ln, ra, item)) continue;
+        int phase = LANE_TRACE;
+        f3 ret = mk3(0, 0, 0);
+        while (phase != LANE_IDLE) {
+            if (phase == LANE_TRACE) {
+                Hit h = closest_hit<EXACT, true, 1>(sc, ln.qo, ln.qd, ln.qtmin, stack.data(), cnt);
+                phase = lane_on_closest(ln, h, ret, sc, ra, frames);
+            } else {
+                for (uint32_t li = 0; li < sc.n_lights; li++) {
+                    f3 o, d;
+                    lane_shadow_query(ln, sc, li, o, d);
+                    Hit h = closest_hit<EXACT, true, 1>(sc, o, d, 0.001f, stack.data(), cnt);
+                    lane_on_shadow(ln, h, o, d, sc, li);
+                }
+                phase = lane_shade(ln, ln.former, ret, sc, ra, frames);
+            }
         }
-        out[st.work] = finish_pixel(st);
-        tot->v[0] += st.rays_path; tot->v[1] += st.rays_shadow; tot->v[2] += st.hit_nodes;
+        samples[ln.slot] = ret;
+        tot->v[0] += ln.rays_path; tot->v[1] += ln.rays_shadow; tot->v[2] += ln.hit_nodes;
     }
     tot->v[3] += cnt.box_tests; tot->v[4] += cnt.sphere_tests; tot->v[5] += cnt.tri_tests; tot->v[6] += cnt.rect_tests;
 }
@@ -115,19 +125,39 @@ int srt_render(srt_ctx* c, const srt_render_params* p, uint32_t* out)
     unsigned n = std::thread::hardware_concurrency();
     if (n < 1) n = 1;
     std::vector<Totals> tot(n);
-    std::vector<std::thread> pool;
     const bool exact = c->world_kind == SRT_WORLD_BVHNODE;
-    // interleave chunks of 64 work items over the threads
-    for (unsigned t = 0; t < n; t++) {
-        pool.emplace_back([&, t]() {
-            for (uint64_t w0 = (uint64_t)t * 64; w0 < ra.n_work; w0 += (uint64_t)n * 64) {
-                uint32_t w1 = (uint32_t)std::min<uint64_t>(w0 + 64, ra.n_work);
-                if (exact) run_range<true>(sc, ra, (uint32_t)w0, w1, out, &tot[t]);
-                else run_range<false>(sc, ra, (uint32_t)w0, w1, out, &tot[t]);
+    // Passes of at most 3 samples, so that the running-sum path of the resolve step is exercised too.
+    const uint32_t per_pass = 3;
+    std::vector<f3> samples((size_t)per_pass * ra.n_work), running(ra.n_work);
+    for (uint32_t s0 = 0; s0 < (uint32_t)ra.samples; s0 += per_pass) {
+        ra.sample_first = s0;
+        ra.sample_count = std::min<uint32_t>(per_pass, (uint32_t)ra.samples - s0);
+        ra.n_items = ra.n_work * ra.sample_count;
+        std::vector<std::thread> pool;
+        for (unsigned t = 0; t < n; t++) {
+            pool.emplace_back([&, t]() {
+                for (uint64_t i0 = (uint64_t)t * 64; i0 < ra.n_items; i0 += (uint64_t)n * 64) {
+                    uint32_t i1 = (uint32_t)std::min<uint64_t>(i0 + 64, ra.n_items);
+                    if (exact) run_items<true>(sc, ra, (uint32_t)i0, i1, samples.data(), &tot[t]);
+                    else run_items<false>(sc, ra, (uint32_t)i0, i1, samples.data(), &tot[t]);
+                }
+            });
+        }
+        for (auto& th : pool) th.join();
+        const bool first = s0 == 0, last = s0 + ra.sample_count >= (uint32_t)ra.samples;
+        for (uint32_t wp = 0; wp < ra.n_work; wp++) {   // what resolve_kernel does per thread
+            int32_t x, y;
+            uint32_t oi;
+            if (!work_to_pixel(ra, wp, x, y, oi)) {
+                if (ra.layout != 0 && last) out[oi] = 0u;
+                continue;
             }
-        });
+            f3 acc = first ? mk3(0.0f, 0.0f, 0.0f) : running[wp];
+            acc = accumulate_samples(acc, samples.data(), ra.n_work, wp, ra.sample_count, 1.0f / (float)ra.samples);
+            if (last) out[oi] = finish_color(acc);
+            else running[wp] = acc;
+        }
     }
-    for (auto& th : pool) th.join();
     uint64_t s[7] = {0, 0, 0, 0, 0, 0, 0};
     for (auto& t : tot) for (int i = 0; i < 7; i++) s[i] += t.v[i];
     c->stats.rays_path = s[0]; c->stats.rays_shadow = s[1]; c->stats.hit_nodes = s[2];

@@ -91,8 +91,8 @@ def lib():
         L.orc_pack_color.restype = C.c_uint32
         L.orc_pack_color.argtypes = [C.c_float, C.c_float, C.c_float]
         L.orc_rng_words.argtypes = [C.c_uint32] * 5 + [C.POINTER(C.c_uint32)]
-        L.orc_rng_next.argtypes = [C.c_uint32, C.c_int, C.c_int]
-        L.orc_random_vector.argtypes = [C.c_uint32] * 5 + [F3]
+        L.orc_rng_next.argtypes = [C.POINTER(C.c_uint32), C.c_int, C.c_int]
+        L.orc_random_vector.argtypes = [C.c_uint32, F3]
         L.orc_hemisphere_vector.argtypes = [C.c_uint32] * 4 + [F3, F3]
         L.orc_angle_between.restype = C.c_float
         L.orc_angle_between.argtypes = [F3, F3]

@@ -132,16 +132,19 @@ inline uint32_t PackColor(float r, float g, float b)
 
 // ---------------------------------------------------------------------------------------
 // Counter-based RNG shared with the GPU kernels (replaces System.Random).
-//   words = pcg4d(pixel, sample, node, slot + 0x9E3779B9 * seed)
-//   Next(lo,hi) = lo + floor(word * (hi-lo) / 2^32)        (System.Random.Next(lo,hi) is
-//                 (int)(Sample() * (hi-lo)) + lo with Sample() uniform in [0,1))
-// Slots inside one ray-tree node: 0 = pixel jitter (node 0 only), 1 = reflection roughness
-// vector, 2+l = shadow jitter of light l, 0x10000+i = i-th try of the unit-sphere rejection loop.
+//   call(key, c):  four words = pcg4d(pixel, sample, node, c + 0x9E3779B9 * seed)
+//   digit(w, B):   d = floor(w * B / 2^32), w <- (w * B) mod 2^32 -- successive base-B digits of the
+//                  fraction w / 2^32, independent and uniform on [0, B).  Random.Next(lo, lo + B)
+//                  (= (int)(Sample() * B) + lo with Sample() uniform in [0,1)) becomes lo + digit.
+// Words inside one ray-tree node: call 0 word 0 = pixel jitter (node 0: two base-100 digits, u
+// first) or the reflection roughness vector (three base-200 digits, X first); word (1+l)&3 of
+// call (1+l)>>2 = shadow jitter of light l; word i&3 of call 0x10000 + (i>>2) = i-th try of the
+// unit-sphere rejection loop.
 // Node ids: primary ray = 1; child k (0 diffuse, 1 metal, 2 reflect) of node n = 4n + k + 1.
 // ---------------------------------------------------------------------------------------
 struct RngKey { uint32_t seed, pixel, sample, node; };
 
-enum : uint32_t { SLOT_JITTER = 0, SLOT_REFLECT = 1, SLOT_LIGHT0 = 2, SLOT_SPHERE0 = 0x10000u };
+enum : uint32_t { CALL_AUX = 0, CALL_SPHERE0 = 0x10000u };
 const int kMaxRejectionTries = 64;  // probability of reaching it: (1 - pi/6)^64 ~ 2e-21
 
 inline void RngWords(const RngKey& k, uint32_t slot, uint32_t w[4])
@@ -156,33 +159,46 @@ inline void RngWords(const RngKey& k, uint32_t slot, uint32_t w[4])
     x += y * t; y += z * x; z += x * y; t += y * z;
     w[0] = x; w[1] = y; w[2] = z; w[3] = t;
 }
-inline int RngNext(uint32_t word, int lo, int hi)
+// random.Next(lo, lo + range): the next base-`range` digit of the word
+inline int RngNext(uint32_t& word, int lo, int range)
 {
-    return lo + (int)(((uint64_t)word * (uint64_t)(uint32_t)(hi - lo)) >> 32);
+    uint64_t p = (uint64_t)word * (uint64_t)(uint32_t)range;
+    word = (uint32_t)p;
+    return lo + (int)(p >> 32);
+}
+// word j of the node's auxiliary calls (j = 0: reflection roughness / jitter, j = 1 + l: light l)
+inline uint32_t AuxWord(const RngKey& k, uint32_t j)
+{
+    uint32_t w[4];
+    RngWords(k, CALL_AUX + (j >> 2), w);
+    return w[j & 3u];
 }
 
 // MiscFunctions.cs:12-15  ReturnRandomVector: three Next(-100,100)/100 draws, X then Y then Z.
-inline Vec ReturnRandomVector(const RngKey& k, uint32_t slot)
+inline Vec ReturnRandomVector(uint32_t word)
 {
-    uint32_t w[4];
-    RngWords(k, slot, w);
-    return V((float)RngNext(w[0], -100, 100) / 100, (float)RngNext(w[1], -100, 100) / 100, (float)RngNext(w[2], -100, 100) / 100);
+    float x = (float)RngNext(word, -100, 200) / 100;
+    float y = (float)RngNext(word, -100, 200) / 100;
+    float z = (float)RngNext(word, -100, 200) / 100;
+    return V(x, y, z);
 }
 // MiscFunctions.cs:18-23
-inline Vec ReturnRandomRangedVector(const RngKey& k, uint32_t slot, float multiplier)
+inline Vec ReturnRandomRangedVector(uint32_t word, float multiplier)
 {
     float factor = 1 - ClampF(multiplier, 0, 1);
-    uint32_t w[4];
-    RngWords(k, slot, w);
-    return V(((float)RngNext(w[0], -100, 100) / 100) * factor, ((float)RngNext(w[1], -100, 100) / 100) * factor,
-             ((float)RngNext(w[2], -100, 100) / 100) * factor);
+    float x = (float)RngNext(word, -100, 200) / 100;
+    float y = (float)RngNext(word, -100, 200) / 100;
+    float z = (float)RngNext(word, -100, 200) / 100;
+    return V(x * factor, y * factor, z * factor);
 }
 // MiscFunctions.cs:26-34 (rejection loop; bounded here, see kMaxRejectionTries)
 inline Vec ReturnRandomUnitSphereVector(const RngKey& k)
 {
     Vec p = V(0, 0, 0);
     for (int i = 0; i < kMaxRejectionTries; i++) {
-        p = ReturnRandomVector(k, SLOT_SPHERE0 + (uint32_t)i);
+        uint32_t w[4];
+        RngWords(k, CALL_SPHERE0 + (uint32_t)(i >> 2), w);
+        p = ReturnRandomVector(w[i & 3]);
         if (DistanceSquared(p, V(0, 0, 0)) >= 1) continue;
         return p;
     }
@@ -605,7 +621,7 @@ struct PointLight : Light {
         // Shadow ray.  It is a closest-hit query that overwrites `record`, so from here on
         // record.point / record.t / record.hitMat belong to the occluder if there is one.
         C().rays_shadow++;
-        if (world->hit(CustomRay(record.point, directionToLight + ReturnRandomRangedVector(key, SLOT_LIGHT0 + lightIndex, 0.95f)),
+        if (world->hit(CustomRay(record.point, directionToLight + ReturnRandomRangedVector(AuxWord(key, 1u + lightIndex), 0.95f)),
                        0.001f, std::numeric_limits<float>::infinity(), record))
             if (Magnitude(CustomRay(record.point, directionToLight).getPos(record.t) - record.point) < Magnitude(position - record.point)) {
                 lightLevel = formerLightLevel;
@@ -682,7 +698,7 @@ Vec GetRayColor(const CustomRay& ray, const Surface* world, RngKey key, int dept
         depth = DepthHeuristic(depth, m.smoothness);
 
         Vec diffuseDirection = record.normal + ReturnHemisphereRandomVector(key, record.normal);
-        Vec reflectedDirection = Reflect(direction, record.normal + ReturnRandomRangedVector(key, SLOT_REFLECT, SqrtF(m.smoothness)));
+        Vec reflectedDirection = Reflect(direction, record.normal + ReturnRandomRangedVector(AuxWord(key, 0), SqrtF(m.smoothness)));
 
         float fresnel = (AngleBetween(direction, reflectedDirection) / 180);
         fresnel *= fresnel;
@@ -799,10 +815,9 @@ void renderBlock(const orc_scene* s, const Surface* world, const orc_camera* cam
             for (int i = 0; i < samples; i++) {
                 key.sample = (uint32_t)i;
                 key.node = 0;
-                uint32_t w[4];
-                RngWords(key, SLOT_JITTER, w);
-                float u = (float)(x + (float)RngNext(w[0], -50, 50) / 100) / p->width;
-                float v = (float)(y + (float)RngNext(w[1], -50, 50) / 100) / p->height;
+                uint32_t jw = AuxWord(key, 0);
+                float u = (float)(x + (float)RngNext(jw, -50, 100) / 100) / p->width;
+                float v = (float)(y + (float)RngNext(jw, -50, 100) / 100) / p->height;
                 CustomRay ray(camPos, llc + u * horiz + v * vert - camPos);
                 key.node = 1;
                 Vec c;
@@ -1049,11 +1064,10 @@ void orc_rng_words(uint32_t seed, uint32_t pixel, uint32_t sample, uint32_t node
     RngKey k{seed, pixel, sample, node};
     RngWords(k, slot, out);
 }
-int orc_rng_next(uint32_t word, int lo, int hi) { return RngNext(word, lo, hi); }
-void orc_random_vector(uint32_t seed, uint32_t pixel, uint32_t sample, uint32_t node, uint32_t slot, float out[3])
+int orc_rng_next(uint32_t* word, int lo, int range) { return RngNext(*word, lo, range); }
+void orc_random_vector(uint32_t word, float out[3])
 {
-    RngKey k{seed, pixel, sample, node};
-    Vec v = ReturnRandomVector(k, slot);
+    Vec v = ReturnRandomVector(word);
     out[0] = v.X; out[1] = v.Y; out[2] = v.Z;
 }
 void orc_hemisphere_vector(uint32_t seed, uint32_t pixel, uint32_t sample, uint32_t node, const float n[3], float out[3])

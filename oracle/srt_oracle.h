@@ -90,9 +90,11 @@ int orc_aabb_hit(const float bmin[3], const float bmax[3], const float o[3], con
 void orc_sky(const float d[3], float rgb[3]);
 int  orc_depth_heuristic(int depth, float smoothness);
 uint32_t orc_pack_color(float r, float g, float b);
-void orc_rng_words(uint32_t seed, uint32_t pixel, uint32_t sample, uint32_t node, uint32_t slot, uint32_t out[4]);
-int  orc_rng_next(uint32_t word, int lo, int hi);
-void orc_random_vector(uint32_t seed, uint32_t pixel, uint32_t sample, uint32_t node, uint32_t slot, float out[3]);
+void orc_rng_words(uint32_t seed, uint32_t pixel, uint32_t sample, uint32_t node, uint32_t call, uint32_t out[4]);
+/* Random.Next(lo, lo + range) as the next base-`range` digit of *word (which is advanced). */
+int  orc_rng_next(uint32_t* word, int lo, int range);
+/* RandomVector.ReturnRandomVector from one RNG word (three base-200 digits). */
+void orc_random_vector(uint32_t word, float out[3]);
 void orc_hemisphere_vector(uint32_t seed, uint32_t pixel, uint32_t sample, uint32_t node, const float n[3], float out[3]);
 float orc_angle_between(const float a[3], const float b[3]);
 /* LightList.calculateLight on a single hit; returns 0 if the primary ray misses. */

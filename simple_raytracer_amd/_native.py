@@ -8,7 +8,7 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-DEFAULT_LIBRARY = os.path.join(_HERE, "csrc", "libsrt.so")
+DEFAULT_LIBRARY = os.environ.get("SRT_LIBRARY") or os.path.join(_HERE, "csrc", "libsrt.so")  # SRT_LIBRARY: experiments only
 
 OK, E_INVALID, E_NO_DEVICE, E_HIP, E_STATE, E_REFERENCE, E_LIMIT = 0, -1, -2, -3, -4, -5, -6
 WORLD_BVHNODE, WORLD_SURFACELIST = 0, 1

@@ -25,7 +25,7 @@ struct srt_ctx {
     int world_kind = SRT_WORLD_BVHNODE;
     Camera cam{};
     bool has_camera = false;
-    q4 *d_nodes = nullptr, *d_prims = nullptr, *d_normals = nullptr, *d_materials = nullptr, *d_lights = nullptr;
+    q4 *d_nodes = nullptr, *d_prims = nullptr, *d_normals = nullptr, *d_materials = nullptr, *d_lights = nullptr, *d_tiny = nullptr;
     uint32_t* d_out = nullptr;
     size_t out_capacity = 0;  // pixels
     unsigned long long* d_stats = nullptr;
@@ -70,8 +70,8 @@ int hip_fail(srt_ctx* c, hipError_t e, const char* what)
 
 void free_scene_buffers(srt_ctx* c)
 {
-    hipFree(c->d_nodes); hipFree(c->d_prims); hipFree(c->d_normals); hipFree(c->d_materials); hipFree(c->d_lights);
-    c->d_nodes = c->d_prims = c->d_normals = c->d_materials = c->d_lights = nullptr;
+    hipFree(c->d_nodes); hipFree(c->d_prims); hipFree(c->d_normals); hipFree(c->d_materials); hipFree(c->d_lights); hipFree(c->d_tiny);
+    c->d_nodes = c->d_prims = c->d_normals = c->d_materials = c->d_lights = c->d_tiny = nullptr;
 }
 
 int upload(srt_ctx* c, const std::vector<q4>& src, q4** dst)
@@ -85,6 +85,7 @@ SceneView scene_view(const srt_ctx* c)
 {
     SceneView v;
     v.nodes = c->d_nodes; v.prims = c->d_prims; v.normals = c->d_normals; v.materials = c->d_materials; v.lights = c->d_lights;
+    v.tiny = c->d_tiny; v.n_tiny = c->flat.n_tiny;
     v.n_lights = c->flat.n_lights; v.list_first = c->flat.list_first; v.list_count = c->flat.list_count; v.has_bvh = c->flat.has_bvh;
     return v;
 }
@@ -310,6 +311,7 @@ int srt_commit_scene(srt_ctx* c, int world_kind)
     if ((rc = upload(c, c->flat.normals, &c->d_normals)) != SRT_OK) return rc;
     if ((rc = upload(c, c->flat.materials, &c->d_materials)) != SRT_OK) return rc;
     if ((rc = upload(c, c->flat.lights, &c->d_lights)) != SRT_OK) return rc;
+    if ((rc = upload(c, c->flat.tiny, &c->d_tiny)) != SRT_OK) return rc;
     c->world_kind = world_kind;
     c->committed = true;
     c->stats.build_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();

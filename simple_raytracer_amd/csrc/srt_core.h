@@ -1,4 +1,5 @@
-// srt_core.h -- the per-path trace loop: ray generation, intersection, BVH traversal, shading.
+// srt_core.h -- building blocks of the trace loop: vector math, RNG, scene records, primitive and
+// box tests, closest-hit queries, hit records and the shading formulas.
 //
 // Everything here is `SRT_HD` (host + device) so that the same source runs inside the gfx950
 // kernels (srt_kernels.hip) and inside a CPU harness used by the tests to debug kernel logic
@@ -81,18 +82,32 @@ SRT_HD uint32_t to_byte(float c)
 SRT_HD uint32_t pack_color(float r, float g, float b) { return to_byte(r) | (to_byte(g) << 8) | (to_byte(b) << 16) | 0xFF000000u; }
 
 // ------------------------------------------------------------------------------------------
-// Counter-based RNG (stands in for System.Random, which the reference seeds from entropy per
-// thread, Game1.cs:44,378).  Four words = pcg4d(pixel, sample, node, slot + 0x9E3779B9*seed);
-// Next(lo,hi) = lo + floor(word*(hi-lo) / 2^32), the integer-quantised draw of Random.Next.
+// Counter-based RNG.  It stands in for System.Random, which the reference seeds from entropy
+// per thread (Game1.cs:44,378) and which therefore cannot be reproduced.
+//
+//   call(key, c)   four 32-bit words = pcg4d(pixel, sample, node, c + 0x9E3779B9 * seed)
+//   digit(w, B)    d = floor(w * B / 2^32), then w <- (w * B) mod 2^32: successive calls peel the
+//                  base-B digits of the fraction w / 2^32, which are independent and uniform on
+//                  [0, B) -- Random.Next(lo, lo + B) is lo + such a digit.
+//   vector(w)      three base-200 digits d1 d2 d3 -> ((d1-100)/100, (d2-100)/100, (d3-100)/100),
+//                  i.e. the three Next(-100,100)/100 draws of RandomVector.ReturnRandomVector
+//                  (MiscFunctions.cs:12-15), X first.
+// Which word feeds what, inside one ray-tree node:
+//   call 0 word 0         the pixel jitter (node 0: two base-100 digits, u first, Game1.cs:283-284)
+//                         or the reflection roughness vector (RaytracingOperations.cs:128)
+//   call (1+l)>>2, word (1+l)&3     the shadow jitter of light l (RaytracingClasses.cs:174)
+//   call 0x10000 + (i>>2), word i&3 the i-th try of the unit-sphere rejection loop (MiscFunctions.cs:26-34)
+// Node ids: primary ray = 1; child k (0 diffuse, 1 metal, 2 reflect) of node n = 4n + k + 1.
+// The value (d-100)/100 is read from a 200-entry table filled with exactly that division.
 // ------------------------------------------------------------------------------------------
-enum : uint32_t { SLOT_JITTER = 0u, SLOT_REFLECT = 1u, SLOT_LIGHT0 = 2u, SLOT_SPHERE0 = 0x10000u };
-enum { MAX_REJECTION_TRIES = 64 };
+enum : uint32_t { CALL_AUX = 0u, CALL_SPHERE0 = 0x10000u };
+enum { MAX_REJECTION_TRIES = 64, UNIT_TABLE = 200 };
 
 struct RngKey { uint32_t seed, pixel, sample, node; };
 
-SRT_HD void rng_words(const RngKey& k, uint32_t slot, uint32_t& a, uint32_t& b, uint32_t& c, uint32_t& d)
+SRT_HD void rng_call(const RngKey& k, uint32_t call, uint32_t w[4])
 {
-    uint32_t x = k.pixel, y = k.sample, z = k.node, t = slot + 0x9E3779B9u * k.seed;
+    uint32_t x = k.pixel, y = k.sample, z = k.node, t = call + 0x9E3779B9u * k.seed;
     x = x * 1664525u + 1013904223u;
     y = y * 1664525u + 1013904223u;
     z = z * 1664525u + 1013904223u;
@@ -100,37 +115,60 @@ SRT_HD void rng_words(const RngKey& k, uint32_t slot, uint32_t& a, uint32_t& b, 
     x += y * t; y += z * x; z += x * y; t += y * z;
     x ^= x >> 16; y ^= y >> 16; z ^= z >> 16; t ^= t >> 16;
     x += y * t; y += z * x; z += x * y; t += y * z;
-    a = x; b = y; c = z; d = t;
+    w[0] = x; w[1] = y; w[2] = z; w[3] = t;
 }
-SRT_HD int rng_next(uint32_t word, int lo, int hi)
+SRT_HD uint32_t rng_digit(uint32_t& w, uint32_t base)
 {
 #if defined(__HIP_DEVICE_COMPILE__)
-    return lo + (int)__umulhi(word, (uint32_t)(hi - lo));
+    uint32_t d = __umulhi(w, base);
+    w = w * base;
+    return d;
 #else
-    return lo + (int)(((uint64_t)word * (uint64_t)(uint32_t)(hi - lo)) >> 32);
+    uint64_t p = (uint64_t)w * (uint64_t)base;
+    w = (uint32_t)p;
+    return (uint32_t)(p >> 32);
 #endif
 }
-// RandomVector.ReturnRandomVector (MiscFunctions.cs:12-15): components k/100, k in [-100, 99]
-SRT_HD f3 random_vector(const RngKey& k, uint32_t slot)
+// entry d of the table: (float)(d - 100) / 100
+SRT_HD void fill_unit_table(float* table)
 {
-    uint32_t a, b, c, d;
-    rng_words(k, slot, a, b, c, d);
-    return mk3((float)rng_next(a, -100, 100) / 100.0f, (float)rng_next(b, -100, 100) / 100.0f, (float)rng_next(c, -100, 100) / 100.0f);
+    for (int d = 0; d < UNIT_TABLE; d++) table[d] = (float)(d - 100) / 100.0f;
+}
+// RandomVector.ReturnRandomVector from one word
+SRT_HD f3 vector_from_word(uint32_t w, const float* unit)
+{
+    uint32_t d1 = rng_digit(w, 200u), d2 = rng_digit(w, 200u), d3 = rng_digit(w, 200u);
+    return mk3(unit[d1], unit[d2], unit[d3]);
 }
 // RandomVector.ReturnRandomRangedVector (MiscFunctions.cs:18-23)
-SRT_HD f3 random_ranged_vector(const RngKey& k, uint32_t slot, float multiplier)
+SRT_HD f3 ranged_vector_from_word(uint32_t w, float multiplier, const float* unit)
 {
     float factor = 1.0f - clampf(multiplier, 0.0f, 1.0f);
-    f3 r = random_vector(k, slot);
+    f3 r = vector_from_word(w, unit);
     return mk3(r.x * factor, r.y * factor, r.z * factor);
 }
-// RandomVector.ReturnHemisphereRandomVector over ReturnRandomUnitSphereVector (MiscFunctions.cs:26-48)
-SRT_HD f3 random_hemisphere_vector(const RngKey& k, f3 normal)
+// word of light l's shadow jitter, given the node's call-0 words
+SRT_HD uint32_t light_word(const RngKey& k, const uint32_t aux[4], uint32_t l)
+{
+    uint32_t j = 1u + l;
+    if (j < 4u) return aux[j];
+    uint32_t w[4];
+    rng_call(k, CALL_AUX + (j >> 2), w);
+    return w[j & 3u];
+}
+// RandomVector.ReturnHemisphereRandomVector over ReturnRandomUnitSphereVector (MiscFunctions.cs:26-48).
+// The rejection loop is bounded at MAX_REJECTION_TRIES (probability of getting there: (1 - pi/6)^64 ~ 2e-21).
+SRT_HD f3 random_hemisphere_vector(const RngKey& k, f3 normal, const float* unit)
 {
     f3 p = mk3(0.0f, 0.0f, 0.0f);
-    for (int i = 0; i < MAX_REJECTION_TRIES; i++) {
-        p = random_vector(k, SLOT_SPHERE0 + (uint32_t)i);
-        if (!(lensq3(p) >= 1.0f)) break;
+    bool found = false;
+    for (uint32_t c = 0; c < (uint32_t)MAX_REJECTION_TRIES / 4u && !found; c++) {
+        uint32_t w[4];
+        rng_call(k, CALL_SPHERE0 + c, w);
+        for (int i = 0; i < 4 && !found; i++) {
+            p = vector_from_word(w[i], unit);
+            found = !(lensq3(p) >= 1.0f);
+        }
     }
     if (dot3(p, normal) > 0.0f) return p;
     return neg3(p);
@@ -142,7 +180,7 @@ SRT_HD f3 random_hemisphere_vector(const RngKey& k, f3 normal)
 enum : uint32_t { PRIM_TRI = 0u, PRIM_SPHERE = 1u, PRIM_RECT = 2u };
 enum : uint32_t { INFO_FLIP = 4u, INFO_BLEND = 8u };
 enum : uint32_t { DESC_LEAF = 0x80000000u, NO_PRIM = 0xFFFFFFFFu };
-enum { STACK_DEPTH = 32, MAX_LEAF_PRIMS = 16, FRAME_SLOTS = 16 };
+enum { STACK_DEPTH = 32, MAX_LEAF_PRIMS = 16, FRAME_SLOTS = 16, TINY_TREE_NODES = 64 };
 
 // Primitive record, 3 words (48 bytes):
 //   tri:    (A.x A.y A.z AB.x) (AB.y AB.z AC.x AC.y) (AC.z  info order normal_index)
@@ -164,6 +202,10 @@ struct SceneView {
     uint32_t n_lights;
     uint32_t list_first, list_count;  // primitives scanned linearly (rects; everything in tiny scenes)
     uint32_t has_bvh;                 // nodes[0] is the root when set
+    // Small reference trees only: the same nodes in depth-first (pre)order, 2 words each:
+    // (min.xyz, desc) (max.xyz, index of the first node after this node's subtree).
+    const q4* tiny;
+    uint32_t n_tiny;
 };
 
 struct Material { f3 albedo; float metalness; float smoothness; f3 emission; };
@@ -301,7 +343,8 @@ SRT_HD bool box_hit_padded(q4 n0, q4 n1, f3 o, f3 inv, float t_best, float& t_ne
 // Closest-hit query = Surface.hit(ray, t_min, +inf, record) on the committed world.
 //   EXACT:  BVHNode.hit order and semantics (left subtree, then right; no distance culling).
 //   !EXACT: SurfaceList.hit semantics through a padded SAH BVH, near child first.
-// STACK: per-lane stack with push/pop (LDS column on the GPU).
+// The per-lane traversal stack lives in `stack_mem` with element stride STRIDE (an LDS column
+// on the GPU).
 // ------------------------------------------------------------------------------------------
 template <int STRIDE>
 struct LaneStack {
@@ -319,6 +362,35 @@ SRT_HD Hit closest_hit(const SceneView& sc, f3 o, f3 d, float t_min, uint32_t* s
     const float a = lensq3(d);  // Sphere.hit's `a`
 
     for (uint32_t i = 0; i < sc.list_count; i++) test_prim<COUNT>(sc, sc.list_first + i, o, d, a, t_min, best, cnt);
+
+    if (EXACT && sc.n_tiny != 0u) {
+        // A reference tree of a few nodes (the Game1 scene has 5): walk the nodes in depth-first order with a
+        // wave-uniform loop.  A lane takes part in node i when its own cursor points at i; a box miss moves the
+        // cursor past the subtree.  Node and primitive data then come from uniform addresses (scalar loads, no
+        // per-lane gathers, no stack), and the visit order, box semantics and tie-breaks are BVHNode.hit's.
+        const f3 inv = mk3(1.0f / d.x, 1.0f / d.y, 1.0f / d.z);
+        uint32_t cur = 0u;
+        q4 n0 = sc.tiny[0], n1 = sc.tiny[1];
+        for (uint32_t i = 0; i < sc.n_tiny; i++) {
+            // fetch the next node while this one is tested (the array has one spare entry at the end)
+            q4 m0 = sc.tiny[2 * i + 2], m1 = sc.tiny[2 * i + 3];
+            if (cur == i) {
+                if (COUNT) cnt.box_tests++;
+                if (box_hit_reference(n0, n1, o, inv)) {
+                    cur = i + 1u;
+                    uint32_t desc = fbits(n0.w);
+                    if (desc & DESC_LEAF) {
+                        uint32_t first = desc & 0x07FFFFFFu, count = ((desc >> 27) & 15u) + 1u;
+                        for (uint32_t k = 0; k < count; k++) test_prim<COUNT>(sc, first + k, o, d, a, t_min, best, cnt);
+                    }
+                } else {
+                    cur = fbits(n1.w);  // first node after this subtree
+                }
+            }
+            n0 = m0; n1 = m1;
+        }
+        return best;
+    }
 
     if (sc.has_bvh) {
         const f3 inv = mk3(1.0f / d.x, 1.0f / d.y, 1.0f / d.z);  // CustomRay.dirFrac (RaytracingClasses.cs:16-18)
@@ -454,12 +526,12 @@ SRT_HD Light load_light(const SceneView& sc, uint32_t i)
     return l;
 }
 
-// Direction of the shadow ray of light `li` from hit point P (RaytracingClasses.cs:105,174):
+// Direction of a light's shadow ray from hit point P (RaytracingClasses.cs:105,174):
 // Normalize(position - P) + ranged(0.95), normalised again by the CustomRay constructor.
-SRT_HD f3 shadow_direction(const Light& L, f3 P, const RngKey& key, uint32_t li)
+SRT_HD f3 shadow_direction(const Light& L, f3 P, uint32_t word, const float* unit)
 {
     f3 to_light = normalize3(sub3(L.position, P));
-    f3 j = random_ranged_vector(key, SLOT_LIGHT0 + li, 0.95f);
+    f3 j = ranged_vector_from_word(word, 0.95f, unit);
     return normalize3(add3(to_light, j));
 }
 
@@ -518,10 +590,7 @@ SRT_HD f3 point_light(const Light& L, f3 P, f3 N, f3 dir, const Material& m, f3 
 }
 
 // ------------------------------------------------------------------------------------------
-// Per-path state machine.  One lane owns one pixel at a time and walks the ray tree of each
-// of its samples depth first; every tree node costs one closest-hit query plus one shadow
-// query per light, and all of them go through the same query slot so that a wavefront always
-// traverses together whatever stage its lanes are in.
+// Render arguments and the work-item <-> pixel mapping
 // ------------------------------------------------------------------------------------------
 struct Camera { f3 position, lower_left, horizontal, vertical; };
 
@@ -549,57 +618,11 @@ struct Frame {
     uint32_t meta; // material | child depth << 24
 };
 
-enum { STAGE_CLOSEST = 0, STAGE_SHADOW = 1, STAGE_DONE = 2 };
 enum : uint32_t { MODE_COLOR = 0u, MODE_NORMAL = 1u, MODE_DEPTH = 2u, MODE_LIGHTS = 3u };
 
-struct PathState {
-    // pixel
-    uint32_t work;      // work item index (for the output address)
-    int32_t px, py;
-    uint32_t sample;
-    f3 pix;             // vectorRayColor of Game1.cs:278
-    // query slot
-    f3 qo, qd;
-    float qtmin;
-    int32_t stage;
-    // current tree node
-    RngKey key;         // key.node = id of the node being evaluated
-    int32_t depth;      // `depth` argument of the current GetRayColor call
-    int32_t level;      // frames in use
-    // hit being lit (valid while stage == STAGE_SHADOW)
-    f3 P, N, dir;
-    uint32_t mat;
-    uint32_t li;
-    f3 former;          // formerLightLevel
-    // counters
-    uint32_t rays_path, rays_shadow, hit_nodes;
-};
-
-// Game1.cs:283-287: jittered viewport coordinates and the primary ray of sample `st.sample`.
-SRT_HD void start_sample(PathState& st, const RenderArgs& ra)
-{
-    st.key.sample = st.sample;
-    st.key.node = 0u;
-    uint32_t a, b, c, d;
-    rng_words(st.key, SLOT_JITTER, a, b, c, d);
-    float u = ((float)st.px + (float)rng_next(a, -50, 50) / 100.0f) / (float)ra.width;
-    float v = ((float)st.py + (float)rng_next(b, -50, 50) / 100.0f) / (float)ra.height;
-    const Camera& cm = ra.cam;
-    f3 dir = mk3(((cm.lower_left.x + u * cm.horizontal.x) + v * cm.vertical.x) - cm.position.x,
-                 ((cm.lower_left.y + u * cm.horizontal.y) + v * cm.vertical.y) - cm.position.y,
-                 ((cm.lower_left.z + u * cm.horizontal.z) + v * cm.vertical.z) - cm.position.z);
-    st.qo = cm.position;
-    st.qd = normalize3(dir);
-    st.qtmin = ((uint32_t)ra.mode == MODE_NORMAL || (uint32_t)ra.mode == MODE_DEPTH) ? 0.0f : 0.01f;
-    st.stage = STAGE_CLOSEST;
-    st.key.node = 1u;
-    st.depth = ra.max_depth;
-    st.level = 0;
-}
-
-// Maps a work item to its pixel.  Work items enumerate this rank's tiles (tile t belongs to
-// rank t % world_size), and inside a tile 8x8 blocks, so that the 64 lanes of a wavefront
-// start on an 8x8 pixel block.  Returns false for padding pixels of edge tiles.
+// Maps a pixel slot of this rank to its pixel.  Slots enumerate this rank's tiles (tile t belongs to
+// rank t % world_size), and inside a tile 8x8 blocks, so that 64 consecutive slots are an 8x8
+// pixel block.  Returns false for padding pixels of edge tiles.
 SRT_HD bool work_to_pixel(const RenderArgs& ra, uint32_t w, int32_t& x, int32_t& y, uint32_t& out_index)
 {
     uint32_t tile_px = (uint32_t)(ra.tile_w * ra.tile_h);
@@ -614,183 +637,6 @@ SRT_HD bool work_to_pixel(const RenderArgs& ra, uint32_t w, int32_t& x, int32_t&
     y = (int32_t)(ty * (uint32_t)ra.tile_h + ly);
     out_index = ra.layout == 0 ? (uint32_t)x + (uint32_t)y * (uint32_t)ra.width : j * tile_px + ly * (uint32_t)ra.tile_w + lx;
     return x < ra.width && y < ra.height && ty < (uint32_t)ra.tiles_y;
-}
-
-SRT_HD void start_pixel(PathState& st, const RenderArgs& ra, uint32_t work, int32_t x, int32_t y)
-{
-    st.work = work; st.px = x; st.py = y;
-    st.key.seed = ra.seed;
-    st.key.pixel = (uint32_t)x + (uint32_t)y * (uint32_t)ra.width;
-    st.sample = 0u;
-    st.pix = mk3(0.0f, 0.0f, 0.0f);
-    start_sample(st, ra);
-}
-
-// Game1.cs:301-306: gamma (sqrt per channel) and packing of a finished pixel.
-SRT_HD uint32_t finish_pixel(const PathState& st) { return pack_color(sqrt_rn(st.pix.x), sqrt_rn(st.pix.y), sqrt_rn(st.pix.z)); }
-
-SRT_HD void begin_light(PathState& st, const SceneView& sc)
-{
-    Light L = load_light(sc, st.li);
-    st.qo = st.P;
-    st.qd = shadow_direction(L, st.P, st.key, st.li);
-    st.qtmin = 0.001f;
-    st.stage = STAGE_SHADOW;
-}
-
-SRT_HD void begin_child(PathState& st, uint32_t child, f3 origin, f3 unit_dir, int32_t depth)
-{
-    st.key.node = st.key.node * 4u + child + 1u;
-    st.qo = origin; st.qd = unit_dir; st.qtmin = 0.01f;
-    st.depth = depth;
-    st.stage = STAGE_CLOSEST;
-}
-
-// Consumes the result of the query in the slot and advances the lane until it has a new
-// query to trace or its pixel is finished.  Returns true when the pixel is finished (st.pix
-// holds the accumulated colour).
-SRT_HD bool advance(PathState& st, const Hit& h, const SceneView& sc, const RenderArgs& ra, Frame* frames)
-{
-    f3 ret;  // value returned by the GetRayColor call that just completed
-    f3 light_color;
-
-    if (st.stage == STAGE_CLOSEST) {
-        const uint32_t mode = (uint32_t)ra.mode;
-        if (mode == MODE_NORMAL || mode == MODE_DEPTH) {
-            // RaytracingOperations.cs:11-35: the miss branch normalises the direction once more
-            if (h.prim != NO_PRIM) {
-                HitRecord r = resolve_hit(sc, h, st.qo, st.qd);
-                if (mode == MODE_NORMAL) ret = mk3(0.5f * (r.normal.x + 1.0f), 0.5f * (r.normal.y + 1.0f), 0.5f * (r.normal.z + 1.0f));
-                else {
-                    float value = sqrt_rn(distsq3(st.qo, r.point));
-                    float c = 1.0f - (0.07f * value);
-                    ret = mk3(c, c, c);
-                }
-            } else {
-                f3 dn = normalize3(st.qd);
-                float t = 0.5f * (dn.y + 1.0f);
-                if (mode == MODE_NORMAL) ret = mk3(t * 0.2f + (1.0f - t) * 0.5f, t * 0.2f + (1.0f - t) * 0.7f, t * 0.2f + (1.0f - t) * 1.0f);
-                else ret = mk3(t * 0.0f, t * 0.0f, t * 0.0f);
-            }
-            goto returned;
-        }
-        if (mode == MODE_LIGHTS) {
-            // GetLights on the primary ray (RaytracingOperations.cs:197-205)
-            if (h.prim == NO_PRIM || sc.n_lights == 0u) { ret = mk3(0.0f, 0.0f, 0.0f); goto returned; }
-        } else {
-            // RaytracingOperations.cs:82-83: depth < 1 returns black before anything is traced (only reachable
-            // for a primary ray with max_depth 0; children are cut off in the spawn step below)
-            if (st.depth < 1) { ret = mk3(0.0f, 0.0f, 0.0f); goto returned; }
-            st.rays_path++;
-            if (h.prim == NO_PRIM) { ret = sky_color(st.qd.y); goto returned; }
-            st.hit_nodes++;
-        }
-        {
-            HitRecord r = resolve_hit(sc, h, st.qo, st.qd);
-            st.P = r.point; st.N = r.normal; st.dir = st.qd; st.mat = r.material;
-            if (mode != MODE_LIGHTS) {
-                q4 mb = sc.materials[2 * r.material + 1];
-                st.depth = depth_heuristic(st.depth, mb.x);
-            }
-            st.former = mk3(0.0f, 0.0f, 0.0f);
-            st.li = 0u;
-            if (sc.n_lights != 0u) { begin_light(st, sc); return false; }
-            light_color = st.former;
-            goto spawn;
-        }
-    } else {
-        // STAGE_SHADOW: the shadow ray of light st.li came back (RaytracingClasses.cs:174-185)
-        st.rays_shadow++;
-        Material m = load_material(sc, st.mat);
-        Light L = load_light(sc, st.li);
-        bool sh = h.prim != NO_PRIM;
-        f3 P_s = st.P;
-        float metal_s = m.metalness;
-        if (sh) {
-            P_s = ray_at(st.qo, st.qd, h.t);
-            metal_s = sc.materials[2 * hit_material(sc, h)].w;
-        }
-        f3 c = point_light(L, st.P, st.N, st.dir, m, st.former, sh, h.t, P_s, metal_s);
-        st.former = add3(st.former, c);  // LightList: formerLightLevel += light.calculateLight(formerLightLevel, ...)
-        st.li++;
-        if (st.li < sc.n_lights) { begin_light(st, sc); return false; }
-        light_color = st.former;
-        if ((uint32_t)ra.mode == MODE_LIGHTS) { ret = light_color; goto returned; }
-    }
-
-spawn:
-    {
-        // RaytracingOperations.cs:119-183 for the node whose lighting just finished
-        Material m = load_material(sc, st.mat);
-        f3 hemi = random_hemisphere_vector(st.key, st.N);
-        f3 diffuse_dir = add3(st.N, hemi);
-        f3 rough = random_ranged_vector(st.key, SLOT_REFLECT, sqrt_rn(m.smoothness));
-        f3 refl = reflect3(st.dir, add3(st.N, rough));
-        float fres = fresnel_term(st.dir, refl);
-        float w_refl = (1.0f - m.metalness) * (fres * (m.smoothness * m.smoothness));
-        int32_t child_depth = st.depth - 1;
-        if (child_depth < 1) {
-            // every child returns Vector3.Zero without tracing (:82-83)
-            f3 zero = mk3(0.0f, 0.0f, 0.0f);
-            f3 wd = scale3(scale3(m.albedo, 1.0f - m.metalness), 0.7f);
-            f3 acc = add3(m.emission, mul3(wd, zero));
-            if (m.metalness != 0.0f) acc = add3(acc, mul3(scale3(m.albedo, m.metalness), zero));
-            if (m.metalness != 1.0f) acc = add3(acc, scale3(zero, w_refl));
-            acc = add3(acc, light_color);
-            ret = mk3(clampf(acc.x, 0.0f, ra.color_clamp), clampf(acc.y, 0.0f, ra.color_clamp), clampf(acc.z, 0.0f, ra.color_clamp));
-            goto returned;
-        }
-        Frame& f = frames[st.level];
-        f.acc = m.emission;
-        f.light = light_color;
-        f.point = st.P;
-        f.refl = normalize3(refl);
-        f.w_refl = w_refl;
-        f.meta = st.mat | ((uint32_t)child_depth << 24);
-        st.level++;
-        begin_child(st, 0u, st.P, normalize3(diffuse_dir), child_depth);
-        return false;
-    }
-
-returned:
-    for (;;) {
-        if (st.level == 0) {
-            // Game1.cs:295: vectorRayColor += vectorColor1 / samples  (Vector3 / float = times 1/samples)
-            float inv = 1.0f / (float)ra.samples;
-            st.pix = mk3(st.pix.x + ret.x * inv, st.pix.y + ret.y * inv, st.pix.z + ret.z * inv);
-            st.sample++;
-            if (st.sample < (uint32_t)ra.samples) { start_sample(st, ra); return false; }
-            st.stage = STAGE_DONE;
-            return true;
-        }
-        Frame& f = frames[st.level - 1];
-        uint32_t mat = f.meta & 0x00FFFFFFu;
-        int32_t child_depth = (int32_t)(f.meta >> 24);
-        Material m = load_material(sc, mat);
-        uint32_t child = (st.key.node & 3u) - 1u;  // which child just returned
-        st.key.node >>= 2;                          // back to the parent's id
-        f3 acc = f.acc;
-        uint32_t next;
-        if (child == 0u) {
-            f3 wd = scale3(scale3(m.albedo, 1.0f - m.metalness), 0.7f);
-            acc = add3(acc, mul3(wd, ret));
-            next = (m.metalness != 0.0f) ? 1u : 2u;
-        } else if (child == 1u) {
-            acc = add3(acc, mul3(scale3(m.albedo, m.metalness), ret));
-            next = (m.metalness != 1.0f) ? 2u : 3u;
-        } else {
-            acc = add3(acc, scale3(ret, f.w_refl));
-            next = 3u;
-        }
-        if (next < 3u) {
-            f.acc = acc;
-            begin_child(st, next, f.point, f.refl, child_depth);
-            return false;
-        }
-        acc = add3(acc, f.light);
-        ret = mk3(clampf(acc.x, 0.0f, ra.color_clamp), clampf(acc.y, 0.0f, ra.color_clamp), clampf(acc.z, 0.0f, ra.color_clamp));
-        st.level--;
-    }
 }
 
 }  // namespace srt

@@ -15,10 +15,16 @@
 // private memory.
 #include <hip/hip_runtime.h>
 
+#include <cstdlib>
+
 #include "srt_launch.h"
 #include "srt_path.h"
 
 namespace srt {
+
+#ifndef SRT_WAVES_PER_SIMD
+#define SRT_WAVES_PER_SIMD 3   // occupancy the register allocator is asked to make room for (measured: 2 -> 25.7 ms, 3 -> 21.1 ms, 4 -> 22.7 ms)
+#endif
 
 constexpr int kBlock = 256;
 constexpr int kWaves = kBlock / 64;
@@ -37,12 +43,16 @@ __device__ __forceinline__ uint32_t lanes_below(unsigned long long mask)
 }
 
 template <bool EXACT, bool COUNT>
-__global__ void __launch_bounds__(kBlock) trace_kernel(SceneView sc, RenderArgs ra, f3* __restrict__ samples,
-                                                       unsigned long long* __restrict__ stats, uint32_t* __restrict__ work_counter)
+__global__ void __launch_bounds__(kBlock, SRT_WAVES_PER_SIMD) trace_kernel(SceneView sc, RenderArgs ra, f3* __restrict__ samples,
+                                                       unsigned long long* __restrict__ stats, uint32_t* __restrict__ work_counter,
+                                                       int trace_vote, uint32_t chunk)
 {
     __shared__ uint32_t lds_stack[kWaves][STACK_DEPTH][64];
+    __shared__ float unit[UNIT_TABLE];   // (d - 100) / 100 for the RNG's base-200 digits
     const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
     uint32_t* my_stack = &lds_stack[wave][0][lane];
+    if (threadIdx.x < (uint32_t)UNIT_TABLE) unit[threadIdx.x] = (float)((int)threadIdx.x - 100) / 100.0f;
+    __syncthreads();
 
     Lane ln;
     Frame frames[FRAME_SLOTS];
@@ -61,16 +71,16 @@ __global__ void __launch_bounds__(kBlock) trace_kernel(SceneView sc, RenderArgs 
             if (next >= end) {
                 if (dry) break;
                 uint32_t base = 0u;
-                if (lane == 0u) base = atomicAdd(work_counter, kChunk);
+                if (lane == 0u) base = atomicAdd(work_counter, chunk);
                 base = __builtin_amdgcn_readfirstlane(base);
                 if (base >= ra.n_items) { dry = true; break; }
                 next = base;
-                end = base + kChunk < ra.n_items ? base + kChunk : ra.n_items;
+                end = base + chunk < ra.n_items ? base + chunk : ra.n_items;
             }
             uint32_t avail = end - next, want = (uint32_t)__popcll(idle);
             uint32_t rank = lanes_below(idle);
             if (phase == LANE_IDLE && rank < avail) {
-                if (item_start(ln, ra, next + rank)) phase = LANE_TRACE;  // padding pixels of edge tiles are skipped
+                if (item_start(ln, ra, next + rank, unit)) phase = LANE_TRACE;  // padding pixels of edge tiles are skipped
             }
             next += want < avail ? want : avail;
             idle = __ballot(phase == LANE_IDLE);
@@ -79,25 +89,27 @@ __global__ void __launch_bounds__(kBlock) trace_kernel(SceneView sc, RenderArgs 
         const int n_light = __popcll(__ballot(phase == LANE_LIGHT));
         if (n_trace + n_light == 0) break;
 
-        if (n_trace >= kTraceVote || n_light == 0) {
+        if (n_trace >= trace_vote || n_light == 0) {
             // ---- TRACE section: closest-hit query of a tree node
             if (phase == LANE_TRACE) {
                 Hit h = closest_hit<EXACT, COUNT, 64>(sc, ln.qo, ln.qd, ln.qtmin, my_stack, cnt);
                 f3 ret;
-                phase = lane_on_closest(ln, h, ret, sc, ra, frames);
+                phase = lane_on_closest(ln, h, ret, sc, ra, frames, unit);
                 if (phase == LANE_IDLE) samples[ln.slot] = ret;
             }
         } else {
             // ---- LIGHT section: one shadow query per light, then the node's shading
             if (phase == LANE_LIGHT) {
+                uint32_t aux[4];
+                rng_call(ln.key, CALL_AUX, aux);
                 for (uint32_t li = 0; li < sc.n_lights; li++) {
                     f3 o, d;
-                    lane_shadow_query(ln, sc, li, o, d);
+                    lane_shadow_query(ln, sc, li, aux, unit, o, d);
                     Hit h = closest_hit<EXACT, COUNT, 64>(sc, o, d, 0.001f, my_stack, cnt);
                     lane_on_shadow(ln, h, o, d, sc, li);
                 }
                 f3 ret;
-                phase = lane_shade(ln, ln.former, ret, sc, ra, frames);
+                phase = lane_shade(ln, ln.former, ret, sc, ra, frames, aux, unit);
                 if (phase == LANE_IDLE) samples[ln.slot] = ret;
             }
         }
@@ -160,16 +172,20 @@ hipError_t launch_trace(const SceneView& sc, const RenderArgs& ra, bool exact, b
     if (ra.n_items == 0u) return hipSuccess;
     hipError_t e = hipMemsetAsync(d_work_counter, 0, sizeof(uint32_t), stream);
     if (e != hipSuccess) return e;
+    // Tuning knobs for experiments; the defaults are the shipped configuration.
+    static const int vote = std::getenv("SRT_TRACE_VOTE") ? std::atoi(std::getenv("SRT_TRACE_VOTE")) : kTraceVote;
+    static const uint32_t chunk = std::getenv("SRT_CHUNK") ? (uint32_t)std::atoi(std::getenv("SRT_CHUNK")) : kChunk;
+    static const uint32_t max_blocks = std::getenv("SRT_MAX_BLOCKS") ? (uint32_t)std::atoi(std::getenv("SRT_MAX_BLOCKS")) : (uint32_t)kMaxBlocks;
     uint32_t blocks = (ra.n_items + kBlock - 1) / kBlock;
-    if (blocks > (uint32_t)kMaxBlocks) blocks = kMaxBlocks;
+    if (blocks > max_blocks) blocks = max_blocks;
     dim3 grid(blocks), block(kBlock);
     f3* s = reinterpret_cast<f3*>(d_samples);
     if (exact) {
-        if (counted) hipLaunchKernelGGL((trace_kernel<true, true>), grid, block, 0, stream, sc, ra, s, d_stats, d_work_counter);
-        else hipLaunchKernelGGL((trace_kernel<true, false>), grid, block, 0, stream, sc, ra, s, d_stats, d_work_counter);
+        if (counted) hipLaunchKernelGGL((trace_kernel<true, true>), grid, block, 0, stream, sc, ra, s, d_stats, d_work_counter, vote, chunk);
+        else hipLaunchKernelGGL((trace_kernel<true, false>), grid, block, 0, stream, sc, ra, s, d_stats, d_work_counter, vote, chunk);
     } else {
-        if (counted) hipLaunchKernelGGL((trace_kernel<false, true>), grid, block, 0, stream, sc, ra, s, d_stats, d_work_counter);
-        else hipLaunchKernelGGL((trace_kernel<false, false>), grid, block, 0, stream, sc, ra, s, d_stats, d_work_counter);
+        if (counted) hipLaunchKernelGGL((trace_kernel<false, true>), grid, block, 0, stream, sc, ra, s, d_stats, d_work_counter, vote, chunk);
+        else hipLaunchKernelGGL((trace_kernel<false, false>), grid, block, 0, stream, sc, ra, s, d_stats, d_work_counter, vote, chunk);
     }
     return hipGetLastError();
 }

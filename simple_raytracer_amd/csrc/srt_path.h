@@ -37,7 +37,7 @@ struct Lane {
 // Work item -> (pixel, sample).  Items enumerate 64-pixel blocks (8x8 pixels of one tile), and inside
 // a block all samples of the pass, 64 pixels at a time, so that 64 consecutive items are one 8x8
 // pixel block at one sample index.  Returns false for padding pixels of edge tiles.
-SRT_HD bool item_start(Lane& ln, const RenderArgs& ra, uint32_t item)
+SRT_HD bool item_start(Lane& ln, const RenderArgs& ra, uint32_t item, const float* unit)
 {
     uint32_t per_block = 64u * ra.sample_count;
     uint32_t blk = item / per_block, r = item - blk * per_block;
@@ -51,11 +51,13 @@ SRT_HD bool item_start(Lane& ln, const RenderArgs& ra, uint32_t item)
     ln.key.pixel = (uint32_t)x + (uint32_t)y * (uint32_t)ra.width;
     ln.key.sample = ra.sample_first + s_local;
     // Game1.cs:283-287: jittered viewport coordinates and the primary ray
+    // (Next(-50,50) / 100f: two base-100 digits of word 0, and (d - 50) / 100 is entry d + 50 of the unit table)
     ln.key.node = 0u;
-    uint32_t a, b, c, d;
-    rng_words(ln.key, SLOT_JITTER, a, b, c, d);
-    float u = ((float)x + (float)rng_next(a, -50, 50) / 100.0f) / (float)ra.width;
-    float v = ((float)y + (float)rng_next(b, -50, 50) / 100.0f) / (float)ra.height;
+    uint32_t w[4];
+    rng_call(ln.key, CALL_AUX, w);
+    uint32_t ju = rng_digit(w[0], 100u), jv = rng_digit(w[0], 100u);
+    float u = ((float)x + unit[ju + 50u]) / (float)ra.width;
+    float v = ((float)y + unit[jv + 50u]) / (float)ra.height;
     const Camera& cm = ra.cam;
     f3 dir = mk3(((cm.lower_left.x + u * cm.horizontal.x) + v * cm.vertical.x) - cm.position.x,
                  ((cm.lower_left.y + u * cm.horizontal.y) + v * cm.vertical.y) - cm.position.y,
@@ -118,13 +120,14 @@ SRT_HD int lane_return(Lane& ln, f3& ret, const SceneView& sc, const RenderArgs&
 
 // All lights of the node are in (light_color = lightColor of RaytracingOperations.cs:144): directions of the
 // children, fresnel, and either the first child or -- when the children would run at depth < 1 -- the node's value.
-SRT_HD int lane_shade(Lane& ln, f3 light_color, f3& ret, const SceneView& sc, const RenderArgs& ra, Frame* frames)
+SRT_HD int lane_shade(Lane& ln, f3 light_color, f3& ret, const SceneView& sc, const RenderArgs& ra, Frame* frames, const uint32_t aux[4],
+                      const float* unit)
 {
     if ((uint32_t)ra.mode == MODE_LIGHTS) { ret = light_color; return LANE_IDLE; }
     Material m = load_material(sc, ln.mat);
-    f3 hemi = random_hemisphere_vector(ln.key, ln.N);
+    f3 hemi = random_hemisphere_vector(ln.key, ln.N, unit);
     f3 diffuse_dir = add3(ln.N, hemi);                                                  // :119
-    f3 rough = random_ranged_vector(ln.key, SLOT_REFLECT, sqrt_rn(m.smoothness));
+    f3 rough = ranged_vector_from_word(aux[0], sqrt_rn(m.smoothness), unit);
     f3 refl = reflect3(ln.qd, add3(ln.N, rough));                                       // :128
     float fres = fresnel_term(ln.qd, refl);                                             // :137-140
     float w_refl = (1.0f - m.metalness) * (fres * (m.smoothness * m.smoothness));
@@ -153,7 +156,7 @@ SRT_HD int lane_shade(Lane& ln, f3 light_color, f3& ret, const SceneView& sc, co
 
 // TRACE phase: the closest-hit query came back.  Returns the lane's next phase; LANE_IDLE means the
 // sample is complete and `ret` is its colour.
-SRT_HD int lane_on_closest(Lane& ln, const Hit& h, f3& ret, const SceneView& sc, const RenderArgs& ra, Frame* frames)
+SRT_HD int lane_on_closest(Lane& ln, const Hit& h, f3& ret, const SceneView& sc, const RenderArgs& ra, Frame* frames, const float* unit)
 {
     const uint32_t mode = (uint32_t)ra.mode;
     if (mode == MODE_NORMAL || mode == MODE_DEPTH) {
@@ -188,16 +191,20 @@ SRT_HD int lane_on_closest(Lane& ln, const Hit& h, f3& ret, const SceneView& sc,
     ln.P = r.point; ln.N = r.normal; ln.mat = r.material;
     if (mode != MODE_LIGHTS) ln.depth = depth_heuristic(ln.depth, sc.materials[2 * r.material + 1].x);
     ln.former = mk3(0.0f, 0.0f, 0.0f);
-    if (sc.n_lights == 0u) return lane_shade(ln, ln.former, ret, sc, ra, frames);
+    if (sc.n_lights == 0u) {
+        uint32_t aux[4];
+        rng_call(ln.key, CALL_AUX, aux);
+        return lane_shade(ln, ln.former, ret, sc, ra, frames, aux, unit);
+    }
     return LANE_LIGHT;
 }
 
 // LIGHT phase, light `li`: its shadow ray ...
-SRT_HD void lane_shadow_query(const Lane& ln, const SceneView& sc, uint32_t li, f3& o, f3& d)
+SRT_HD void lane_shadow_query(const Lane& ln, const SceneView& sc, uint32_t li, const uint32_t aux[4], const float* unit, f3& o, f3& d)
 {
     Light L = load_light(sc, li);
     o = ln.P;
-    d = shadow_direction(L, ln.P, ln.key, li);
+    d = shadow_direction(L, ln.P, light_word(ln.key, aux, li), unit);
 }
 // ... and its contribution once the shadow ray (o, d) came back: formerLightLevel += calculateLight(formerLightLevel, ...)
 SRT_HD void lane_on_shadow(Lane& ln, const Hit& h, f3 o, f3 d, const SceneView& sc, uint32_t li)

@@ -361,6 +361,20 @@ void emit_prim(const HostScene& in, uint32_t g, uint32_t order, std::vector<q4>&
     }
 }
 
+// Depth-first (pre)order copy of a small tree with skip indices, for the wave-uniform walk.
+void emit_tiny(const std::vector<NodeRec>& nodes, uint32_t idx, std::vector<q4>& out)
+{
+    const NodeRec& n = nodes[idx];
+    size_t at = out.size();
+    out.push_back(mkq(n.box.mn[0], n.box.mn[1], n.box.mn[2], bitsf(n.desc)));
+    out.push_back(mkq(n.box.mx[0], n.box.mx[1], n.box.mx[2], 0.0f));
+    if (!(n.desc & DESC_LEAF)) {
+        emit_tiny(nodes, n.desc, out);
+        emit_tiny(nodes, n.desc + 1, out);
+    }
+    out[at + 1].w = bitsf((uint32_t)(out.size() / 2));  // first node after this subtree
+}
+
 void emit_nodes(const std::vector<NodeRec>& nodes, std::vector<q4>& out)
 {
     out.reserve(nodes.size() * 2);
@@ -526,6 +540,12 @@ int flatten_scene(const HostScene& in, int world_kind, FlatScene& out, std::stri
             emit_nodes(b.nodes, out.nodes);
             out.n_nodes = (uint32_t)b.nodes.size();
             out.bvh_depth = b.max_depth;
+            if (b.nodes.size() <= (size_t)TINY_TREE_NODES) {
+                emit_tiny(b.nodes, 0, out.tiny);
+                out.n_tiny = (uint32_t)(out.tiny.size() / 2);
+                out.tiny.push_back(mkq(0, 0, 0, 0));  // one spare node: the walk fetches one node ahead
+                out.tiny.push_back(mkq(0, 0, 0, 0));
+            }
         } else {
             SahBuilder b(pb);
             b.run();
@@ -552,6 +572,7 @@ int flatten_scene(const HostScene& in, int world_kind, FlatScene& out, std::stri
     if (out.normals.empty()) out.normals.assign(3, zero);
     if (out.materials.empty()) out.materials.assign(2, zero);
     if (out.lights.empty()) out.lights.assign(2, zero);
+    if (out.tiny.empty()) out.tiny.assign(4, zero);
     return SRT_OK;
 }
 

@@ -31,8 +31,8 @@ struct HostScene {
 
 // Device-ready arrays in the layout srt_core.h documents.
 struct FlatScene {
-    std::vector<q4> nodes, prims, normals, materials, lights;
-    uint32_t n_lights = 0, list_first = 0, list_count = 0, has_bvh = 0;
+    std::vector<q4> nodes, prims, normals, materials, lights, tiny;
+    uint32_t n_lights = 0, list_first = 0, list_count = 0, has_bvh = 0, n_tiny = 0;
     uint32_t n_nodes = 0, bvh_depth = 0, n_prims = 0;
 };
 

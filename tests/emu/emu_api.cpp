@@ -40,25 +40,29 @@ void run_items(const SceneView& sc, const RenderArgs& ra, uint32_t i0, uint32_t 
 {
     std::vector<uint32_t> stack(STACK_DEPTH);
     Counters cnt{0, 0, 0, 0};
+    float unit[UNIT_TABLE];
+    fill_unit_table(unit);
     for (uint32_t item = i0; item < i1; item++) {
         Lane ln;
         Frame frames[FRAME_SLOTS];
         ln.rays_path = ln.rays_shadow = ln.hit_nodes = 0u;
-        if (!item_start(ln, ra, item)) continue;
+        if (!item_start(ln, ra, item, unit)) continue;
         int phase = LANE_TRACE;
         f3 ret = mk3(0, 0, 0);
         while (phase != LANE_IDLE) {
             if (phase == LANE_TRACE) {
                 Hit h = closest_hit<EXACT, true, 1>(sc, ln.qo, ln.qd, ln.qtmin, stack.data(), cnt);
-                phase = lane_on_closest(ln, h, ret, sc, ra, frames);
+                phase = lane_on_closest(ln, h, ret, sc, ra, frames, unit);
             } else {
+                uint32_t aux[4];
+                rng_call(ln.key, CALL_AUX, aux);
                 for (uint32_t li = 0; li < sc.n_lights; li++) {
                     f3 o, d;
-                    lane_shadow_query(ln, sc, li, o, d);
+                    lane_shadow_query(ln, sc, li, aux, unit, o, d);
                     Hit h = closest_hit<EXACT, true, 1>(sc, o, d, 0.001f, stack.data(), cnt);
                     lane_on_shadow(ln, h, o, d, sc, li);
                 }
-                phase = lane_shade(ln, ln.former, ret, sc, ra, frames);
+                phase = lane_shade(ln, ln.former, ret, sc, ra, frames, aux, unit);
             }
         }
         samples[ln.slot] = ret;
@@ -121,6 +125,7 @@ int srt_render(srt_ctx* c, const srt_render_params* p, uint32_t* out)
     SceneView sc;
     sc.nodes = c->flat.nodes.data(); sc.prims = c->flat.prims.data(); sc.normals = c->flat.normals.data();
     sc.materials = c->flat.materials.data(); sc.lights = c->flat.lights.data();
+    sc.tiny = c->flat.tiny.data(); sc.n_tiny = c->flat.n_tiny;
     sc.n_lights = c->flat.n_lights; sc.list_first = c->flat.list_first; sc.list_count = c->flat.list_count; sc.has_bvh = c->flat.has_bvh;
     unsigned n = std::thread::hardware_concurrency();
     if (n < 1) n = 1;

@@ -22,7 +22,7 @@ enum { P_DIV, P_SQRT, P_NORMALIZE, P_REFLECT, P_FRESNEL, P_POINT_LIGHT, P_SPHERE
 static const char* kNames[P_COUNT] = {"div", "sqrt", "normalize", "reflect", "fresnel", "point_light", "sphere", "tri", "rng",
                                       "hemisphere", "sky_pack", "pow5", "atan2"};
 
-SRT_HD void eval(int which, const float* in, float* out)
+SRT_HD void eval(int which, const float* in, float* out, const float* unit)
 {
     for (int i = 0; i < OUT; i++) out[i] = 0.0f;
     f3 a = mk3(in[0], in[1], in[2]), b = mk3(in[3], in[4], in[5]), c = mk3(in[6], in[7], in[8]);
@@ -56,12 +56,15 @@ SRT_HD void eval(int which, const float* in, float* out)
         }
         case P_RNG: {
             RngKey k; k.seed = fbits(in[0]); k.pixel = fbits(in[1]); k.sample = fbits(in[2]); k.node = fbits(in[3]);
-            f3 r = random_vector(k, fbits(in[4]) & 0xFFFFu); out[0] = r.x; out[1] = r.y; out[2] = r.z;
-            f3 q = random_ranged_vector(k, 1u, 0.95f); out[3] = q.x; out[4] = q.y; out[5] = q.z; break;
+            uint32_t w[4];
+            rng_call(k, fbits(in[4]) & 0xFFFFu, w);
+            f3 r = vector_from_word(w[0], unit); out[0] = r.x; out[1] = r.y; out[2] = r.z;
+            f3 q = ranged_vector_from_word(w[1], 0.95f, unit); out[3] = q.x; out[4] = q.y; out[5] = q.z;
+            out[6] = bitsf(w[2]); out[7] = bitsf(light_word(k, w, 5u)); break;
         }
         case P_HEMI: {
             RngKey k; k.seed = 1u; k.pixel = fbits(in[1]); k.sample = fbits(in[2]) & 1023u; k.node = 1u + (fbits(in[3]) & 255u);
-            f3 r = random_hemisphere_vector(k, normalize3(a)); out[0] = r.x; out[1] = r.y; out[2] = r.z; break;
+            f3 r = random_hemisphere_vector(k, normalize3(a), unit); out[0] = r.x; out[1] = r.y; out[2] = r.z; break;
         }
         case P_SKY_PACK: { f3 s = sky_color(in[0]); out[0] = s.x; out[1] = s.y; out[2] = s.z; out[3] = bitsf(pack_color(in[1], in[2] * 2.0f, sqrt_rn(fabsf(in[3])))); break; }
         case P_POW5: { double x = (double)(1.0f - fabsf(in[0])); double x2 = x * x; out[0] = (float)(x2 * x2 * x); break; }
@@ -71,8 +74,11 @@ SRT_HD void eval(int which, const float* in, float* out)
 
 __global__ void probe_kernel(int which, const float* in, float* out, int n)
 {
+    __shared__ float unit[UNIT_TABLE];
+    if (threadIdx.x < (unsigned)UNIT_TABLE) unit[threadIdx.x] = (float)((int)threadIdx.x - 100) / 100.0f;
+    __syncthreads();
     int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < n) eval(which, in + (size_t)i * IN, out + (size_t)i * OUT);
+    if (i < n) eval(which, in + (size_t)i * IN, out + (size_t)i * OUT, unit);
 }
 
 int main()
@@ -89,7 +95,9 @@ int main()
         hipLaunchKernelGGL(probe_kernel, dim3((N + 255) / 256), dim3(256), 0, 0, which, d_in, d_out, N);
         if (hipDeviceSynchronize() != hipSuccess) { printf("kernel failed\n"); return 2; }
         hipMemcpy(dev.data(), d_out, dev.size() * 4, hipMemcpyDeviceToHost);
-        for (int i = 0; i < N; i++) eval(which, &in[(size_t)i * IN], &host[(size_t)i * OUT]);
+        float unit[UNIT_TABLE];
+        fill_unit_table(unit);
+        for (int i = 0; i < N; i++) eval(which, &in[(size_t)i * IN], &host[(size_t)i * OUT], unit);
         int bad = 0, first = -1;
         for (int i = 0; i < N; i++) {
             bool same = true;

@@ -177,20 +177,39 @@ def test_counter_rng_matches_its_definition(oracle):
         seed, pixel, sample, node, slot = [int(v) for v in rng.integers(0, 2 ** 32, size=5)]
         L.orc_rng_words(seed, pixel, sample, node, slot, out)
         assert list(out) == _pcg4d(pixel, sample, node, (slot + 0x9E3779B9 * seed) & 0xFFFFFFFF)
-    # Next(lo, hi) = lo + floor(word * (hi - lo) / 2^32): covers [lo, hi) and nothing else
-    assert L.orc_rng_next(0, -100, 100) == -100 and L.orc_rng_next(0xFFFFFFFF, -100, 100) == 99
-    assert L.orc_rng_next(0x80000000, -50, 50) == 0 and L.orc_rng_next(0xFFFFFFFF, -50, 50) == 49
+    # Next(lo, lo + B) = lo + next base-B digit of word / 2^32: covers [lo, lo + B) and nothing else
+    for word, lo, rng_, want in ((0, -100, 200, -100), (0xFFFFFFFF, -100, 200, 99), (0x80000000, -50, 100, 0), (0xFFFFFFFF, -50, 100, 49)):
+        w = C.c_uint32(word)
+        assert L.orc_rng_next(C.byref(w), lo, rng_) == want
+    # successive draws from one word are the base-B digits of word / 2^32: 0.(100)(50)(7)... in base 200
+    w = C.c_uint32(int((100 + (50 + (7 + 0.5) / 200) / 200) / 200 * 2 ** 32))
+    assert [L.orc_rng_next(C.byref(w), 0, 200) for _ in range(3)] == [100, 50, 7]
+    # ... and they are uniform and pairwise independent (chi-square over a 20 x 20 coarse grid of (d1, d2), (d2, d3))
+    rng = np.random.default_rng(1)
+    counts = np.zeros((2, 20, 20))
+    n = 200000
+    for word in rng.integers(0, 2 ** 32, size=n):
+        w = C.c_uint32(int(word))
+        d = [L.orc_rng_next(C.byref(w), 0, 200) for _ in range(3)]
+        counts[0, d[0] // 10, d[1] // 10] += 1
+        counts[1, d[1] // 10, d[2] // 10] += 1
+    expected = n / 400.0
+    chi2 = ((counts - expected) ** 2 / expected).sum(axis=(1, 2))
+    assert (chi2 < 399 + 6 * np.sqrt(2 * 399)).all(), chi2   # 399 degrees of freedom, 6 sigma
 
 
 def test_random_vector_helpers(oracle):
     L = oracle.lib()
     v = (C.c_float * 3)()
+    words = (C.c_uint32 * 4)()
     grid = {np.float32(k) / np.float32(100) for k in range(-100, 100)}
     seen = set()
-    for i in range(2000):
-        L.orc_random_vector(5, i, 0, 1, 1, v)
-        assert all(np.float32(c) in grid for c in v)
-        seen.update(np.float32(c) for c in v)
+    for i in range(500):
+        L.orc_rng_words(5, i, 0, 1, 1, words)
+        for w in words:
+            L.orc_random_vector(w, v)
+            assert all(np.float32(c) in grid for c in v)
+            seen.update(np.float32(c) for c in v)
     assert len(seen) == 200                                  # every value of Next(-100,100)/100 shows up
     n = oracle.f3((0.0, -0.6, 0.8))
     for i in range(2000):

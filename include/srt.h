@@ -111,6 +111,9 @@ typedef struct {
     uint32_t bvh_depth;
     uint32_t n_prims;
     uint32_t reserved;
+    /* Wavefront occupancy of the trace kernel (only filled by srt_render_counted): how often a wavefront ran its
+       closest-hit section / its light section, and how many of the 64 lanes took part, summed. */
+    uint64_t trace_sections, trace_lanes, light_sections, light_lanes;
 } srt_stats;
 
 typedef struct srt_ctx srt_ctx;

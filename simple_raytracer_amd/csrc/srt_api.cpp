@@ -83,11 +83,7 @@ int upload(srt_ctx* c, const std::vector<q4>& src, q4** dst)
 
 SceneView scene_view(const srt_ctx* c)
 {
-    SceneView v;
-    v.nodes = c->d_nodes; v.prims = c->d_prims; v.normals = c->d_normals; v.materials = c->d_materials; v.lights = c->d_lights;
-    v.tiny = c->d_tiny; v.n_tiny = c->flat.n_tiny;
-    v.n_lights = c->flat.n_lights; v.list_first = c->flat.list_first; v.list_count = c->flat.list_count; v.has_bvh = c->flat.has_bvh;
-    return v;
+    return c->flat.view(c->d_nodes, c->d_prims, c->d_normals, c->d_materials, c->d_lights, c->d_tiny);
 }
 
 // Fetches (and zeroes) the counters accumulated by the launches since the last collection, once
@@ -96,7 +92,7 @@ int collect_stats(srt_ctx* c)
 {
     if (!c->stats_pending) return SRT_OK;
     SRT_HIP(c, hipEventSynchronize(c->ev_end));
-    unsigned long long s[8];
+    unsigned long long s[12];
     SRT_HIP(c, hipMemcpy(s, c->d_stats, sizeof(s), hipMemcpyDeviceToHost));
     SRT_HIP(c, hipMemsetAsync(c->d_stats, 0, sizeof(s), c->stream));
     SRT_HIP(c, hipStreamSynchronize(c->stream));
@@ -104,6 +100,7 @@ int collect_stats(srt_ctx* c)
     SRT_HIP(c, hipEventElapsedTime(&ms, c->ev_begin, c->ev_end));
     c->stats.rays_path = s[0]; c->stats.rays_shadow = s[1]; c->stats.hit_nodes = s[2];
     c->stats.box_tests = s[3]; c->stats.sphere_tests = s[4]; c->stats.tri_tests = s[5]; c->stats.rect_tests = s[6];
+    c->stats.trace_sections = s[7]; c->stats.trace_lanes = s[8]; c->stats.light_sections = s[9]; c->stats.light_lanes = s[10];
     c->stats.kernel_ms = ms;
     c->stats_pending = false;
     return SRT_OK;
@@ -219,9 +216,9 @@ int srt_create(const srt_config* cfg, srt_ctx** out)
     c->device = device;
     bool ok = hipSetDevice(device) == hipSuccess && hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) == hipSuccess &&
               hipEventCreate(&c->ev_begin) == hipSuccess && hipEventCreate(&c->ev_end) == hipSuccess &&
-              hipMalloc((void**)&c->d_stats, 8 * sizeof(unsigned long long)) == hipSuccess &&
+              hipMalloc((void**)&c->d_stats, 12 * sizeof(unsigned long long)) == hipSuccess &&
               hipMalloc((void**)&c->d_counter, sizeof(uint32_t)) == hipSuccess &&
-              hipMemset(c->d_stats, 0, 8 * sizeof(unsigned long long)) == hipSuccess && hipDeviceSynchronize() == hipSuccess;
+              hipMemset(c->d_stats, 0, 12 * sizeof(unsigned long long)) == hipSuccess && hipDeviceSynchronize() == hipSuccess;
     if (!ok) {
         srt_destroy(c);
         return fail(nullptr, SRT_E_HIP, "could not create stream / events / counters on the device");

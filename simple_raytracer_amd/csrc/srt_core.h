@@ -206,6 +206,10 @@ struct SceneView {
     // (min.xyz, desc) (max.xyz, index of the first node after this node's subtree).
     const q4* tiny;
     uint32_t n_tiny;
+    uint32_t n_nodes, n_prims, n_materials;  // table sizes (nodes / primitive records / materials)
+    // The primitive records again, for the per-lane lookups of the winning hit (same data as `prims`; the kernels
+    // point it at an LDS copy when the scene is small).
+    const q4* hit_prims;
 };
 
 struct Material { f3 albedo; float metalness; float smoothness; f3 emission; };
@@ -446,19 +450,19 @@ struct HitRecord { f3 point, normal; uint32_t material; };
 
 SRT_HD f3 ray_at(f3 o, f3 d, float t) { return mk3(o.x + (t * d.x), o.y + (t * d.y), o.z + (t * d.z)); }  // CustomRay.getPos
 
-SRT_HD uint32_t hit_material(const SceneView& sc, const Hit& h) { return fbits(sc.prims[3 * h.prim + 2].y) >> 8; }
+SRT_HD uint32_t hit_material(const SceneView& sc, const Hit& h) { return fbits(sc.hit_prims[3 * h.prim + 2].y) >> 8; }
 
 SRT_HD HitRecord resolve_hit(const SceneView& sc, const Hit& h, f3 o, f3 d)
 {
     HitRecord r;
-    q4 p2 = sc.prims[3 * h.prim + 2];
+    q4 p2 = sc.hit_prims[3 * h.prim + 2];
     uint32_t info = fbits(p2.y);
     uint32_t type = info & 3u;
     r.material = info >> 8;
     r.point = ray_at(o, d, h.t);
     if (type == PRIM_SPHERE) {
         // RaytracingClasses.cs:482-483: Normalize((point - origin) / radius), flipped to face the ray
-        q4 s = sc.prims[3 * h.prim];
+        q4 s = sc.hit_prims[3 * h.prim];
         float f = 1.0f / s.w;
         f3 n = normalize3(mk3((r.point.x - s.x) * f, (r.point.y - s.y) * f, (r.point.z - s.z) * f));
         bool front = dot3(d, n) < 0.0f;
@@ -473,7 +477,7 @@ SRT_HD HitRecord resolve_hit(const SceneView& sc, const Hit& h, f3 o, f3 d)
             n = mk3(a.x + (b.x - a.x) * h.u + (c.x - a.x) * h.v, a.y + (b.y - a.y) * h.u + (c.y - a.y) * h.v,
                     a.z + (b.z - a.z) * h.u + (c.z - a.z) * h.v);
         } else {
-            q4 p0 = sc.prims[3 * h.prim], p1 = sc.prims[3 * h.prim + 1];
+            q4 p0 = sc.hit_prims[3 * h.prim], p1 = sc.hit_prims[3 * h.prim + 1];
             n = cross3(mk3(p0.w, p1.x, p1.y), mk3(p1.z, p1.w, p2.x));
         }
         n = normalize3(n);

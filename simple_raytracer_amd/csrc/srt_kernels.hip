@@ -16,6 +16,7 @@
 #include <hip/hip_runtime.h>
 
 #include <cstdlib>
+#include <type_traits>
 
 #include "srt_launch.h"
 #include "srt_path.h"
@@ -42,25 +43,60 @@ __device__ __forceinline__ uint32_t lanes_below(unsigned long long mask)
     return __builtin_amdgcn_mbcnt_hi((uint32_t)(mask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mask, 0u));
 }
 
-template <bool EXACT, bool COUNT>
-__global__ void __launch_bounds__(kBlock, SRT_WAVES_PER_SIMD) trace_kernel(SceneView sc, RenderArgs ra, f3* __restrict__ samples,
+// SMALL kernels serve scenes that need no traversal stack (a reference tree of a few nodes, walked with the
+// wave-uniform loop, or a handful of surfaces scanned linearly) and whose primitive and material tables fit the
+// limits below.  Their LDS holds those two tables (they are indexed per lane) and the deepest kLdsFrameLevels
+// levels of every lane's ray-tree frames instead of the stack.
+constexpr uint32_t kSmallPrims = 64, kSmallMaterials = 64;
+constexpr int kLdsFrameLevels = 3;
+constexpr uint32_t kSmallPrimWords = 3 * kSmallPrims, kSmallMatWords = 2 * kSmallMaterials;
+constexpr uint32_t kSmallWords = kSmallPrimWords + kSmallMatWords;
+
+__device__ __forceinline__ void copy_words(q4* dst, const q4* src, uint32_t n)
+{
+    for (uint32_t i = threadIdx.x; i < n; i += kBlock) dst[i] = src[i];
+}
+
+template <bool EXACT, bool COUNT, bool SMALL>
+__global__ void __launch_bounds__(kBlock, SRT_WAVES_PER_SIMD) trace_kernel(SceneView gsc, RenderArgs ra, f3* __restrict__ samples,
                                                        unsigned long long* __restrict__ stats, uint32_t* __restrict__ work_counter,
                                                        int trace_vote, uint32_t chunk)
 {
-    __shared__ uint32_t lds_stack[kWaves][STACK_DEPTH][64];
+    __shared__ uint32_t lds_stack[SMALL ? 1 : kWaves * STACK_DEPTH * 64];
+    __shared__ float lds_frames[SMALL ? kWaves * kLdsFrameLevels * 14 * 64 : 1];
     __shared__ float unit[UNIT_TABLE];   // (d - 100) / 100 for the RNG's base-200 digits
+    __shared__ q4 small_tables[SMALL ? kSmallWords : 1];
     const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
-    uint32_t* my_stack = &lds_stack[wave][0][lane];
+    uint32_t* my_stack = SMALL ? lds_stack : &lds_stack[wave * (STACK_DEPTH * 64) + lane];
     if (threadIdx.x < (uint32_t)UNIT_TABLE) unit[threadIdx.x] = (float)((int)threadIdx.x - 100) / 100.0f;
+    SceneView sc = gsc;
+    if (SMALL) {
+        // Only the tables that are indexed per lane go to LDS: the material of a hit and the record of the winning
+        // primitive.  Nodes, lights and the primitives tested by wave-uniform loops stay behind scalar loads, which
+        // keep them in SGPRs instead of spending a VGPR per value.
+        q4* prims = small_tables;
+        q4* mats = prims + kSmallPrimWords;
+        copy_words(prims, gsc.prims, 3u * gsc.n_prims);
+        copy_words(mats, gsc.materials, 2u * gsc.n_materials);
+        sc.hit_prims = prims; sc.materials = mats;
+    }
     __syncthreads();
 
     Lane ln;
-    Frame frames[FRAME_SLOTS];
+    Frame frame_mem[FRAME_SLOTS];
+    typename std::conditional<SMALL, HybridFrames<kLdsFrameLevels>, PrivateFrames>::type frames;
+    frames.a = frame_mem;
+    if constexpr (SMALL) {
+        // frames in use are levels 0 .. max_depth-2; the last kLdsFrameLevels of them live in LDS
+        frames.lds = &lds_frames[wave * (kLdsFrameLevels * 14 * 64) + lane];
+        frames.first = ra.max_depth - 1 - kLdsFrameLevels > 0 ? ra.max_depth - 1 - kLdsFrameLevels : 0;
+    }
     Counters cnt;
     cnt.box_tests = cnt.sphere_tests = cnt.tri_tests = cnt.rect_tests = 0u;
     ln.rays_path = ln.rays_shadow = ln.hit_nodes = 0u;
     int phase = LANE_IDLE;
 
+    uint32_t sect[4] = {0u, 0u, 0u, 0u};  // counting builds: section executions and the lanes that took part
     uint32_t next = 0u, end = 0u;  // wave-uniform: the wavefront's private range of items
     bool dry = false;              // wave-uniform: the global counter is exhausted
 
@@ -91,6 +127,7 @@ __global__ void __launch_bounds__(kBlock, SRT_WAVES_PER_SIMD) trace_kernel(Scene
 
         if (n_trace >= trace_vote || n_light == 0) {
             // ---- TRACE section: closest-hit query of a tree node
+            if (COUNT) { sect[0]++; sect[1] += (uint32_t)n_trace; }
             if (phase == LANE_TRACE) {
                 Hit h = closest_hit<EXACT, COUNT, 64>(sc, ln.qo, ln.qd, ln.qtmin, my_stack, cnt);
                 f3 ret;
@@ -99,6 +136,7 @@ __global__ void __launch_bounds__(kBlock, SRT_WAVES_PER_SIMD) trace_kernel(Scene
             }
         } else {
             // ---- LIGHT section: one shadow query per light, then the node's shading
+            if (COUNT) { sect[2]++; sect[3] += (uint32_t)n_light; }
             if (phase == LANE_LIGHT) {
                 uint32_t aux[4];
                 rng_call(ln.key, CALL_AUX, aux);
@@ -128,6 +166,7 @@ __global__ void __launch_bounds__(kBlock, SRT_WAVES_PER_SIMD) trace_kernel(Scene
             atomicAdd(&stats[4], c1);
             atomicAdd(&stats[5], c2);
             atomicAdd(&stats[6], c3);
+            for (int i = 0; i < 4; i++) atomicAdd(&stats[7 + i], (unsigned long long)sect[i]);
         }
     }
 }
@@ -180,13 +219,18 @@ hipError_t launch_trace(const SceneView& sc, const RenderArgs& ra, bool exact, b
     if (blocks > max_blocks) blocks = max_blocks;
     dim3 grid(blocks), block(kBlock);
     f3* s = reinterpret_cast<f3*>(d_samples);
+    static const bool allow_small = !std::getenv("SRT_NO_LDS_SCENE");
+    const bool stackless = sc.has_bvh == 0u || (exact && sc.n_tiny != 0u);
+    const bool small = allow_small && stackless && sc.n_prims <= kSmallPrims && sc.n_materials <= kSmallMaterials;
+#define SRT_LAUNCH(E, C, S) hipLaunchKernelGGL((trace_kernel<E, C, S>), grid, block, 0, stream, sc, ra, s, d_stats, d_work_counter, vote, chunk)
     if (exact) {
-        if (counted) hipLaunchKernelGGL((trace_kernel<true, true>), grid, block, 0, stream, sc, ra, s, d_stats, d_work_counter, vote, chunk);
-        else hipLaunchKernelGGL((trace_kernel<true, false>), grid, block, 0, stream, sc, ra, s, d_stats, d_work_counter, vote, chunk);
+        if (counted) { if (small) SRT_LAUNCH(true, true, true); else SRT_LAUNCH(true, true, false); }
+        else { if (small) SRT_LAUNCH(true, false, true); else SRT_LAUNCH(true, false, false); }
     } else {
-        if (counted) hipLaunchKernelGGL((trace_kernel<false, true>), grid, block, 0, stream, sc, ra, s, d_stats, d_work_counter, vote, chunk);
-        else hipLaunchKernelGGL((trace_kernel<false, false>), grid, block, 0, stream, sc, ra, s, d_stats, d_work_counter, vote, chunk);
+        if (counted) { if (small) SRT_LAUNCH(false, true, true); else SRT_LAUNCH(false, true, false); }
+        else { if (small) SRT_LAUNCH(false, false, true); else SRT_LAUNCH(false, false, false); }
     }
+#undef SRT_LAUNCH
     return hipGetLastError();
 }
 

@@ -71,6 +71,56 @@ SRT_HD bool item_start(Lane& ln, const RenderArgs& ra, uint32_t item, const floa
     return true;
 }
 
+// Where the frames of pending parents live.  Both stores hold the same Frame per level; they differ in the memory
+// behind a level.
+//   PrivateFrames   an array in private memory (the CPU harness, and GPU scenes that need their LDS for traversal);
+//   HybridFrames    the deepest LDS_LEVELS levels of the recursion in LDS (most tree nodes sit at the bottom of the
+//                   tree, so most pushes and pops are there), laid out [level][field][lane] so that the 64 lanes of a
+//                   wavefront hit 64 different banks; shallower levels in private memory.
+struct PrivateFrames {
+    Frame* a;
+    SRT_HD Frame load(int32_t level) const { return a[level]; }
+    SRT_HD void store(int32_t level, const Frame& f) const { a[level] = f; }
+    SRT_HD void store_acc(int32_t level, f3 acc) const { a[level].acc = acc; }
+};
+
+template <int LDS_LEVELS>
+struct HybridFrames {
+    Frame* a;          // private memory, all levels
+    float* lds;        // this lane's column of the wavefront's LDS slab
+    int32_t first;     // first level kept in LDS
+    SRT_HD Frame load(int32_t level) const
+    {
+        if (level < first) return a[level];
+        const float* p = lds + (level - first) * (14 * 64);
+        Frame f;
+        f.acc = mk3(p[0 * 64], p[1 * 64], p[2 * 64]);
+        f.light = mk3(p[3 * 64], p[4 * 64], p[5 * 64]);
+        f.point = mk3(p[6 * 64], p[7 * 64], p[8 * 64]);
+        f.refl = mk3(p[9 * 64], p[10 * 64], p[11 * 64]);
+        f.w_refl = p[12 * 64];
+        f.meta = fbits(p[13 * 64]);
+        return f;
+    }
+    SRT_HD void store(int32_t level, const Frame& f) const
+    {
+        if (level < first) { a[level] = f; return; }
+        float* p = lds + (level - first) * (14 * 64);
+        p[0 * 64] = f.acc.x; p[1 * 64] = f.acc.y; p[2 * 64] = f.acc.z;
+        p[3 * 64] = f.light.x; p[4 * 64] = f.light.y; p[5 * 64] = f.light.z;
+        p[6 * 64] = f.point.x; p[7 * 64] = f.point.y; p[8 * 64] = f.point.z;
+        p[9 * 64] = f.refl.x; p[10 * 64] = f.refl.y; p[11 * 64] = f.refl.z;
+        p[12 * 64] = f.w_refl;
+        p[13 * 64] = bitsf(f.meta);
+    }
+    SRT_HD void store_acc(int32_t level, f3 acc) const
+    {
+        if (level < first) { a[level].acc = acc; return; }
+        float* p = lds + (level - first) * (14 * 64);
+        p[0 * 64] = acc.x; p[1 * 64] = acc.y; p[2 * 64] = acc.z;
+    }
+};
+
 SRT_HD void lane_begin_child(Lane& ln, uint32_t child, f3 origin, f3 unit_dir, int32_t depth)
 {
     ln.key.node = ln.key.node * 4u + child + 1u;
@@ -83,10 +133,11 @@ SRT_HD f3 clamp_color(f3 c, float hi) { return mk3(clampf(c.x, 0.0f, hi), clampf
 // The GetRayColor call of node ln.key.node returned `ret`: hand it to the parent, start the next
 // child or complete parents up the tree.  Returns LANE_TRACE with a new query, or LANE_IDLE
 // with `ret` holding the colour of the whole sample.
-SRT_HD int lane_return(Lane& ln, f3& ret, const SceneView& sc, const RenderArgs& ra, Frame* frames)
+template <class FRAMES>
+SRT_HD int lane_return(Lane& ln, f3& ret, const SceneView& sc, const RenderArgs& ra, const FRAMES& frames)
 {
     while (ln.level > 0) {
-        Frame& f = frames[ln.level - 1];
+        const Frame f = frames.load(ln.level - 1);
         uint32_t mat = f.meta & 0x00FFFFFFu;
         int32_t child_depth = (int32_t)(f.meta >> 24);
         Material m = load_material(sc, mat);
@@ -108,7 +159,7 @@ SRT_HD int lane_return(Lane& ln, f3& ret, const SceneView& sc, const RenderArgs&
             next = 3u;
         }
         if (next < 3u) {
-            f.acc = acc;
+            frames.store_acc(ln.level - 1, acc);
             lane_begin_child(ln, next, f.point, f.refl, child_depth);
             return LANE_TRACE;
         }
@@ -120,7 +171,8 @@ SRT_HD int lane_return(Lane& ln, f3& ret, const SceneView& sc, const RenderArgs&
 
 // All lights of the node are in (light_color = lightColor of RaytracingOperations.cs:144): directions of the
 // children, fresnel, and either the first child or -- when the children would run at depth < 1 -- the node's value.
-SRT_HD int lane_shade(Lane& ln, f3 light_color, f3& ret, const SceneView& sc, const RenderArgs& ra, Frame* frames, const uint32_t aux[4],
+template <class FRAMES>
+SRT_HD int lane_shade(Lane& ln, f3 light_color, f3& ret, const SceneView& sc, const RenderArgs& ra, const FRAMES& frames, const uint32_t aux[4],
                       const float* unit)
 {
     if ((uint32_t)ra.mode == MODE_LIGHTS) { ret = light_color; return LANE_IDLE; }
@@ -142,13 +194,14 @@ SRT_HD int lane_shade(Lane& ln, f3 light_color, f3& ret, const SceneView& sc, co
         ret = clamp_color(add3(acc, light_color), ra.color_clamp);
         return lane_return(ln, ret, sc, ra, frames);
     }
-    Frame& f = frames[ln.level];
+    Frame f;
     f.acc = m.emission;
     f.light = light_color;
     f.point = ln.P;
     f.refl = normalize3(refl);  // CustomRay normalises; the metal and the reflect child share the direction
     f.w_refl = w_refl;
     f.meta = ln.mat | ((uint32_t)child_depth << 24);
+    frames.store(ln.level, f);
     ln.level++;
     lane_begin_child(ln, 0u, ln.P, normalize3(diffuse_dir), child_depth);
     return LANE_TRACE;
@@ -156,7 +209,8 @@ SRT_HD int lane_shade(Lane& ln, f3 light_color, f3& ret, const SceneView& sc, co
 
 // TRACE phase: the closest-hit query came back.  Returns the lane's next phase; LANE_IDLE means the
 // sample is complete and `ret` is its colour.
-SRT_HD int lane_on_closest(Lane& ln, const Hit& h, f3& ret, const SceneView& sc, const RenderArgs& ra, Frame* frames, const float* unit)
+template <class FRAMES>
+SRT_HD int lane_on_closest(Lane& ln, const Hit& h, f3& ret, const SceneView& sc, const RenderArgs& ra, const FRAMES& frames, const float* unit)
 {
     const uint32_t mode = (uint32_t)ra.mode;
     if (mode == MODE_NORMAL || mode == MODE_DEPTH) {

@@ -518,6 +518,7 @@ int flatten_scene(const HostScene& in, int world_kind, FlatScene& out, std::stri
         out.lights.push_back(mkq(l.color[0], l.color[1], l.color[2], 0.0f));
     }
     out.n_lights = (uint32_t)in.lights.size();
+    out.n_materials = nm;
     out.normals.reserve((size_t)nt * 3);
     for (uint32_t i = 0; i < nt; i++) {
         const float* n = &in.tri_nrm[(size_t)i * 9];

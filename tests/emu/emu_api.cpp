@@ -44,7 +44,9 @@ void run_items(const SceneView& sc, const RenderArgs& ra, uint32_t i0, uint32_t 
     fill_unit_table(unit);
     for (uint32_t item = i0; item < i1; item++) {
         Lane ln;
-        Frame frames[FRAME_SLOTS];
+        Frame frame_mem[FRAME_SLOTS];
+        PrivateFrames frames;
+        frames.a = frame_mem;
         ln.rays_path = ln.rays_shadow = ln.hit_nodes = 0u;
         if (!item_start(ln, ra, item, unit)) continue;
         int phase = LANE_TRACE;
@@ -122,11 +124,8 @@ int srt_render(srt_ctx* c, const srt_render_params* p, uint32_t* out)
     RenderArgs ra;
     int rc = make_render_args(p, c->cam, ra, c->error);
     if (rc != SRT_OK) return rc;
-    SceneView sc;
-    sc.nodes = c->flat.nodes.data(); sc.prims = c->flat.prims.data(); sc.normals = c->flat.normals.data();
-    sc.materials = c->flat.materials.data(); sc.lights = c->flat.lights.data();
-    sc.tiny = c->flat.tiny.data(); sc.n_tiny = c->flat.n_tiny;
-    sc.n_lights = c->flat.n_lights; sc.list_first = c->flat.list_first; sc.list_count = c->flat.list_count; sc.has_bvh = c->flat.has_bvh;
+    SceneView sc = c->flat.view(c->flat.nodes.data(), c->flat.prims.data(), c->flat.normals.data(), c->flat.materials.data(),
+                                c->flat.lights.data(), c->flat.tiny.data());
     unsigned n = std::thread::hardware_concurrency();
     if (n < 1) n = 1;
     std::vector<Totals> tot(n);

@@ -114,6 +114,9 @@ typedef struct {
     /* Wavefront occupancy of the trace kernel (only filled by srt_render_counted): how often a wavefront ran its
        closest-hit section / its light section, and how many of the 64 lanes took part, summed. */
     uint64_t trace_sections, trace_lanes, light_sections, light_lanes;
+    /* Shader-clock cycles summed over wavefronts (only filled by srt_render_counted): dealing work items, the
+       closest-hit query, the bookkeeping after it, the shadow queries, the shading after them. */
+    uint64_t section_cycles[5];
 } srt_stats;
 
 typedef struct srt_ctx srt_ctx;

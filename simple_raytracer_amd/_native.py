@@ -46,7 +46,8 @@ class Stats(C.Structure):
                 ("sphere_tests", C.c_uint64), ("tri_tests", C.c_uint64), ("rect_tests", C.c_uint64),
                 ("kernel_ms", C.c_double), ("build_ms", C.c_double),
                 ("bvh_nodes", C.c_uint32), ("bvh_depth", C.c_uint32), ("n_prims", C.c_uint32), ("reserved", C.c_uint32),
-                ("trace_sections", C.c_uint64), ("trace_lanes", C.c_uint64), ("light_sections", C.c_uint64), ("light_lanes", C.c_uint64)]
+                ("trace_sections", C.c_uint64), ("trace_lanes", C.c_uint64), ("light_sections", C.c_uint64), ("light_lanes", C.c_uint64),
+                ("section_cycles", C.c_uint64 * 5)]
 
 
 # every symbol include/srt.h declares: (name, restype, argtypes)

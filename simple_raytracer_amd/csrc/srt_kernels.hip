@@ -45,7 +45,7 @@ __device__ __forceinline__ uint32_t lanes_below(unsigned long long mask)
 
 // SMALL kernels serve scenes that need no traversal stack (a reference tree of a few nodes, walked with the
 // wave-uniform loop, or a handful of surfaces scanned linearly) and whose primitive and material tables fit the
-// limits below.  Their LDS holds those two tables (they are indexed per lane) and the deepest kLdsFrameLevels
+// limits below.  Their LDS holds those two tables (they are indexed per lane) and the first kLdsFrameLevels
 // levels of every lane's ray-tree frames instead of the stack.
 constexpr uint32_t kSmallPrims = 64, kSmallMaterials = 64;
 constexpr int kLdsFrameLevels = 3;
@@ -87,9 +87,7 @@ __global__ void __launch_bounds__(kBlock, SRT_WAVES_PER_SIMD) trace_kernel(Scene
     typename std::conditional<SMALL, HybridFrames<kLdsFrameLevels>, PrivateFrames>::type frames;
     frames.a = frame_mem;
     if constexpr (SMALL) {
-        // frames in use are levels 0 .. max_depth-2; the last kLdsFrameLevels of them live in LDS
         frames.lds = &lds_frames[wave * (kLdsFrameLevels * 14 * 64) + lane];
-        frames.first = ra.max_depth - 1 - kLdsFrameLevels > 0 ? ra.max_depth - 1 - kLdsFrameLevels : 0;
     }
     Counters cnt;
     cnt.box_tests = cnt.sphere_tests = cnt.tri_tests = cnt.rect_tests = 0u;
@@ -97,45 +95,58 @@ __global__ void __launch_bounds__(kBlock, SRT_WAVES_PER_SIMD) trace_kernel(Scene
     int phase = LANE_IDLE;
 
     uint32_t sect[4] = {0u, 0u, 0u, 0u};  // counting builds: section executions and the lanes that took part
+    unsigned long long cyc[5] = {0ull, 0ull, 0ull, 0ull, 0ull}, t_mark = 0ull;   // counting builds: shader clock per part
+#define SRT_MARK(i) do { if (COUNT) { unsigned long long t_now = __builtin_readcyclecounter(); cyc[i] += t_now - t_mark; t_mark = t_now; } } while (0)
     uint32_t next = 0u, end = 0u;  // wave-uniform: the wavefront's private range of items
     bool dry = false;              // wave-uniform: the global counter is exhausted
 
     for (;;) {
-        // ---- deal items to idle lanes
-        unsigned long long idle = __ballot(phase == LANE_IDLE);
-        while (idle != 0ull) {
-            if (next >= end) {
-                if (dry) break;
-                uint32_t base = 0u;
-                if (lane == 0u) base = atomicAdd(work_counter, chunk);
-                base = __builtin_amdgcn_readfirstlane(base);
-                if (base >= ra.n_items) { dry = true; break; }
-                next = base;
-                end = base + chunk < ra.n_items ? base + chunk : ra.n_items;
-            }
-            uint32_t avail = end - next, want = (uint32_t)__popcll(idle);
-            uint32_t rank = lanes_below(idle);
-            if (phase == LANE_IDLE && rank < avail) {
-                if (item_start(ln, ra, next + rank, unit)) phase = LANE_TRACE;  // padding pixels of edge tiles are skipped
-            }
-            next += want < avail ? want : avail;
-            idle = __ballot(phase == LANE_IDLE);
-        }
-        const int n_trace = __popcll(__ballot(phase == LANE_TRACE));
+        if (COUNT) t_mark = __builtin_readcyclecounter();
+        const int n_trace = __popcll(__ballot(phase == LANE_TRACE || phase == LANE_RETURN || (phase == LANE_IDLE && !dry)));
         const int n_light = __popcll(__ballot(phase == LANE_LIGHT));
         if (n_trace + n_light == 0) break;
 
         if (n_trace >= trace_vote || n_light == 0) {
-            // ---- TRACE section: closest-hit query of a tree node
-            if (COUNT) { sect[0]++; sect[1] += (uint32_t)n_trace; }
+            // ---- RETURN: values travel up the tree until a parent starts its next child or the sample is complete
+            if (phase == LANE_RETURN) {
+                f3 ret;
+                phase = lane_return(ln, ret, sc, ra, frames);
+                if (phase == LANE_IDLE) samples[ln.slot] = ret;
+            }
+            SRT_MARK(2);
+            // ---- deal items to idle lanes
+            unsigned long long idle = __ballot(phase == LANE_IDLE);
+            while (idle != 0ull) {
+                if (next >= end) {
+                    if (dry) break;
+                    uint32_t base = 0u;
+                    if (lane == 0u) base = atomicAdd(work_counter, chunk);
+                    base = __builtin_amdgcn_readfirstlane(base);
+                    if (base >= ra.n_items) { dry = true; break; }
+                    next = base;
+                    end = base + chunk < ra.n_items ? base + chunk : ra.n_items;
+                }
+                uint32_t avail = end - next, want = (uint32_t)__popcll(idle);
+                uint32_t rank = lanes_below(idle);
+                if (phase == LANE_IDLE && rank < avail) {
+                    if (item_start(ln, ra, next + rank, unit)) phase = LANE_TRACE;  // padding pixels of edge tiles are skipped
+                }
+                next += want < avail ? want : avail;
+                idle = __ballot(phase == LANE_IDLE);
+            }
+            SRT_MARK(0);
+            // ---- TRACE: closest-hit query of a tree node
+            if (COUNT) { sect[0]++; sect[1] += (uint32_t)__popcll(__ballot(phase == LANE_TRACE)); }
             if (phase == LANE_TRACE) {
                 Hit h = closest_hit<EXACT, COUNT, 64>(sc, ln.qo, ln.qd, ln.qtmin, my_stack, cnt);
+                SRT_MARK(1);
                 f3 ret;
                 phase = lane_on_closest(ln, h, ret, sc, ra, frames, unit);
                 if (phase == LANE_IDLE) samples[ln.slot] = ret;
             }
+            SRT_MARK(2);
         } else {
-            // ---- LIGHT section: one shadow query per light, then the node's shading
+            // ---- LIGHT: one shadow query per light, then the node's shading
             if (COUNT) { sect[2]++; sect[3] += (uint32_t)n_light; }
             if (phase == LANE_LIGHT) {
                 uint32_t aux[4];
@@ -146,10 +157,12 @@ __global__ void __launch_bounds__(kBlock, SRT_WAVES_PER_SIMD) trace_kernel(Scene
                     Hit h = closest_hit<EXACT, COUNT, 64>(sc, o, d, 0.001f, my_stack, cnt);
                     lane_on_shadow(ln, h, o, d, sc, li);
                 }
+                SRT_MARK(3);
                 f3 ret;
                 phase = lane_shade(ln, ln.former, ret, sc, ra, frames, aux, unit);
                 if (phase == LANE_IDLE) samples[ln.slot] = ret;
             }
+            SRT_MARK(4);
         }
     }
 
@@ -167,6 +180,7 @@ __global__ void __launch_bounds__(kBlock, SRT_WAVES_PER_SIMD) trace_kernel(Scene
             atomicAdd(&stats[5], c2);
             atomicAdd(&stats[6], c3);
             for (int i = 0; i < 4; i++) atomicAdd(&stats[7 + i], (unsigned long long)sect[i]);
+            for (int i = 0; i < 5; i++) atomicAdd(&stats[11 + i], cyc[i]);
         }
     }
 }

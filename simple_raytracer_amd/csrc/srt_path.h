@@ -5,13 +5,15 @@
 // a sample buffer; a second kernel adds the samples of each pixel in index order, which is the
 // order Game1.cs:281-296 adds them in, so the float sum is the same.
 //
-// A lane is in one of two phases:
-//   TRACE  it holds the closest-hit query of a tree node (world.hit(ray, 0.01, inf, record));
-//   LIGHT  the node was hit: it still owes one shadow query per light (LightList.calculateLight,
-//          RaytracingClasses.cs:205-218) and then the node's shading, which either starts the
-//          first child (back to TRACE) or completes nodes up the tree.
-// The kernel runs the two phases as separate, wave-wide code sections, so that lanes which
-// execute a section all execute the same code.
+// A lane is in one of three phases:
+//   TRACE   it holds the closest-hit query of a tree node (world.hit(ray, 0.01, inf, record));
+//   LIGHT   the node was hit: it still owes one shadow query per light (LightList.calculateLight,
+//           RaytracingClasses.cs:205-218) and then the node's shading, which either starts the
+//           first child (back to TRACE) or finds that the node has no children to trace (RETURN);
+//   RETURN  a GetRayColor call has its value (a miss, or a node without traced children): it is handed
+//           up the tree until some parent has another child to start (TRACE) or the sample is done.
+// The kernel runs the phases as separate, wave-wide code sections, so that lanes which execute a
+// section all execute the same code.
 #ifndef SRT_PATH_H
 #define SRT_PATH_H
 
@@ -19,7 +21,7 @@
 
 namespace srt {
 
-enum { LANE_IDLE = 0, LANE_TRACE = 1, LANE_LIGHT = 2 };
+enum { LANE_IDLE = 0, LANE_TRACE = 1, LANE_LIGHT = 2, LANE_RETURN = 3 };
 
 struct Lane {
     uint32_t slot;      // where the sample's colour goes in the sample buffer
@@ -30,7 +32,7 @@ struct Lane {
     float qtmin;
     f3 P, N;            // hit being lit (LIGHT)
     uint32_t mat;
-    f3 former;          // formerLightLevel
+    f3 former;          // formerLightLevel (LIGHT) / the value being returned (RETURN)
     uint32_t rays_path, rays_shadow, hit_nodes;
 };
 
@@ -74,9 +76,10 @@ SRT_HD bool item_start(Lane& ln, const RenderArgs& ra, uint32_t item, const floa
 // Where the frames of pending parents live.  Both stores hold the same Frame per level; they differ in the memory
 // behind a level.
 //   PrivateFrames   an array in private memory (the CPU harness, and GPU scenes that need their LDS for traversal);
-//   HybridFrames    the deepest LDS_LEVELS levels of the recursion in LDS (most tree nodes sit at the bottom of the
-//                   tree, so most pushes and pops are there), laid out [level][field][lane] so that the 64 lanes of a
-//                   wavefront hit 64 different banks; shallower levels in private memory.
+//   HybridFrames    the first LDS_LEVELS levels of the recursion in LDS (the depth heuristic ends most branches of the
+//                   ray tree after a few levels, so more than half of all pushes and pops are there), laid out
+//                   [level][field][lane] so that the 64 lanes of a wavefront hit 64 different banks; deeper levels in
+//                   private memory.
 struct PrivateFrames {
     Frame* a;
     SRT_HD Frame load(int32_t level) const { return a[level]; }
@@ -88,11 +91,10 @@ template <int LDS_LEVELS>
 struct HybridFrames {
     Frame* a;          // private memory, all levels
     float* lds;        // this lane's column of the wavefront's LDS slab
-    int32_t first;     // first level kept in LDS
     SRT_HD Frame load(int32_t level) const
     {
-        if (level < first) return a[level];
-        const float* p = lds + (level - first) * (14 * 64);
+        if (level >= LDS_LEVELS) return a[level];
+        const float* p = lds + level * (14 * 64);
         Frame f;
         f.acc = mk3(p[0 * 64], p[1 * 64], p[2 * 64]);
         f.light = mk3(p[3 * 64], p[4 * 64], p[5 * 64]);
@@ -104,8 +106,8 @@ struct HybridFrames {
     }
     SRT_HD void store(int32_t level, const Frame& f) const
     {
-        if (level < first) { a[level] = f; return; }
-        float* p = lds + (level - first) * (14 * 64);
+        if (level >= LDS_LEVELS) { a[level] = f; return; }
+        float* p = lds + level * (14 * 64);
         p[0 * 64] = f.acc.x; p[1 * 64] = f.acc.y; p[2 * 64] = f.acc.z;
         p[3 * 64] = f.light.x; p[4 * 64] = f.light.y; p[5 * 64] = f.light.z;
         p[6 * 64] = f.point.x; p[7 * 64] = f.point.y; p[8 * 64] = f.point.z;
@@ -115,8 +117,8 @@ struct HybridFrames {
     }
     SRT_HD void store_acc(int32_t level, f3 acc) const
     {
-        if (level < first) { a[level].acc = acc; return; }
-        float* p = lds + (level - first) * (14 * 64);
+        if (level >= LDS_LEVELS) { a[level].acc = acc; return; }
+        float* p = lds + level * (14 * 64);
         p[0 * 64] = acc.x; p[1 * 64] = acc.y; p[2 * 64] = acc.z;
     }
 };
@@ -130,12 +132,13 @@ SRT_HD void lane_begin_child(Lane& ln, uint32_t child, f3 origin, f3 unit_dir, i
 
 SRT_HD f3 clamp_color(f3 c, float hi) { return mk3(clampf(c.x, 0.0f, hi), clampf(c.y, 0.0f, hi), clampf(c.z, 0.0f, hi)); }
 
-// The GetRayColor call of node ln.key.node returned `ret`: hand it to the parent, start the next
-// child or complete parents up the tree.  Returns LANE_TRACE with a new query, or LANE_IDLE
+// RETURN phase: the GetRayColor call of node ln.key.node returned ln.former: hand it to the parent, start
+// the next child or complete parents up the tree.  Returns LANE_TRACE with a new query, or LANE_IDLE
 // with `ret` holding the colour of the whole sample.
 template <class FRAMES>
 SRT_HD int lane_return(Lane& ln, f3& ret, const SceneView& sc, const RenderArgs& ra, const FRAMES& frames)
 {
+    ret = ln.former;
     while (ln.level > 0) {
         const Frame f = frames.load(ln.level - 1);
         uint32_t mat = f.meta & 0x00FFFFFFu;
@@ -170,7 +173,8 @@ SRT_HD int lane_return(Lane& ln, f3& ret, const SceneView& sc, const RenderArgs&
 }
 
 // All lights of the node are in (light_color = lightColor of RaytracingOperations.cs:144): directions of the
-// children, fresnel, and either the first child or -- when the children would run at depth < 1 -- the node's value.
+// children, fresnel, and either the first child (LANE_TRACE) or -- when the children would run at depth < 1 -- the
+// node's value in ln.former (LANE_RETURN).  LANE_IDLE with `ret` set ends the sample (lights-only mode).
 template <class FRAMES>
 SRT_HD int lane_shade(Lane& ln, f3 light_color, f3& ret, const SceneView& sc, const RenderArgs& ra, const FRAMES& frames, const uint32_t aux[4],
                       const float* unit)
@@ -191,8 +195,8 @@ SRT_HD int lane_shade(Lane& ln, f3 light_color, f3& ret, const SceneView& sc, co
         f3 acc = add3(m.emission, mul3(wd, zero));
         if (m.metalness != 0.0f) acc = add3(acc, mul3(scale3(m.albedo, m.metalness), zero));
         if (m.metalness != 1.0f) acc = add3(acc, scale3(zero, w_refl));
-        ret = clamp_color(add3(acc, light_color), ra.color_clamp);
-        return lane_return(ln, ret, sc, ra, frames);
+        ln.former = clamp_color(add3(acc, light_color), ra.color_clamp);
+        return LANE_RETURN;
     }
     Frame f;
     f.acc = m.emission;
@@ -208,7 +212,7 @@ SRT_HD int lane_shade(Lane& ln, f3 light_color, f3& ret, const SceneView& sc, co
 }
 
 // TRACE phase: the closest-hit query came back.  Returns the lane's next phase; LANE_IDLE means the
-// sample is complete and `ret` is its colour.
+// sample is complete and `ret` is its colour, LANE_RETURN that ln.former holds the node's value.
 template <class FRAMES>
 SRT_HD int lane_on_closest(Lane& ln, const Hit& h, f3& ret, const SceneView& sc, const RenderArgs& ra, const FRAMES& frames, const float* unit)
 {
@@ -236,9 +240,9 @@ SRT_HD int lane_on_closest(Lane& ln, const Hit& h, f3& ret, const SceneView& sc,
         if (h.prim == NO_PRIM || sc.n_lights == 0u) { ret = mk3(0.0f, 0.0f, 0.0f); return LANE_IDLE; }
     } else {
         // :82-83: depth < 1 returns black before anything is traced (a primary ray with max_depth 0)
-        if (ln.depth < 1) { ret = mk3(0.0f, 0.0f, 0.0f); return lane_return(ln, ret, sc, ra, frames); }
+        if (ln.depth < 1) { ln.former = mk3(0.0f, 0.0f, 0.0f); return LANE_RETURN; }
         ln.rays_path++;
-        if (h.prim == NO_PRIM) { ret = sky_color(ln.qd.y); return lane_return(ln, ret, sc, ra, frames); }
+        if (h.prim == NO_PRIM) { ln.former = sky_color(ln.qd.y); return LANE_RETURN; }
         ln.hit_nodes++;
     }
     HitRecord r = resolve_hit(sc, h, ln.qo, ln.qd);

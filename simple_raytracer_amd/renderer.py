@@ -125,7 +125,9 @@ class Renderer:
     def stats(self):
         st = N.Stats()
         self._check(self._lib.srt_get_stats(self._ctx, C.byref(st)))
-        return {k: getattr(st, k) for k, _ in N.Stats._fields_ if k != "reserved"}
+        out = {k: getattr(st, k) for k, _ in N.Stats._fields_ if k != "reserved"}
+        out["section_cycles"] = list(st.section_cycles)
+        return out
 
 
 def rgba_to_rgb8(img):

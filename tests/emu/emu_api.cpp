@@ -52,7 +52,9 @@ void run_items(const SceneView& sc, const RenderArgs& ra, uint32_t i0, uint32_t 
         int phase = LANE_TRACE;
         f3 ret = mk3(0, 0, 0);
         while (phase != LANE_IDLE) {
-            if (phase == LANE_TRACE) {
+            if (phase == LANE_RETURN) {
+                phase = lane_return(ln, ret, sc, ra, frames);
+            } else if (phase == LANE_TRACE) {
                 Hit h = closest_hit<EXACT, true, 1>(sc, ln.qo, ln.qd, ln.qtmin, stack.data(), cnt);
                 phase = lane_on_closest(ln, h, ret, sc, ra, frames, unit);
             } else {

@@ -114,9 +114,11 @@ typedef struct {
     /* Wavefront occupancy of the trace kernel (only filled by srt_render_counted): how often a wavefront ran its
        closest-hit section / its light section, and how many of the 64 lanes took part, summed. */
     uint64_t trace_sections, trace_lanes, light_sections, light_lanes;
-    /* Shader-clock cycles summed over wavefronts (only filled by srt_render_counted): dealing work items, the
-       closest-hit query, the bookkeeping after it, the shadow queries, the shading after them. */
-    uint64_t section_cycles[5];
+    /* Shader-clock cycles summed over wavefronts (only filled by srt_render_counted), by part of the kernel:
+       0 dealing work items, 1 handing values up the tree, 2 closest-hit query, 3 bookkeeping after it,
+       4 random words of a lit node, 5 shadow-ray set-up, 6 shadow query, 7 light evaluation,
+       8 child directions, 9 fresnel, 10 starting a child / finishing a leaf; 11-15 unused. */
+    uint64_t section_cycles[16];
 } srt_stats;
 
 typedef struct srt_ctx srt_ctx;

@@ -92,7 +92,7 @@ int collect_stats(srt_ctx* c)
 {
     if (!c->stats_pending) return SRT_OK;
     SRT_HIP(c, hipEventSynchronize(c->ev_end));
-    unsigned long long s[16];
+    unsigned long long s[32];
     SRT_HIP(c, hipMemcpy(s, c->d_stats, sizeof(s), hipMemcpyDeviceToHost));
     SRT_HIP(c, hipMemsetAsync(c->d_stats, 0, sizeof(s), c->stream));
     SRT_HIP(c, hipStreamSynchronize(c->stream));
@@ -101,7 +101,7 @@ int collect_stats(srt_ctx* c)
     c->stats.rays_path = s[0]; c->stats.rays_shadow = s[1]; c->stats.hit_nodes = s[2];
     c->stats.box_tests = s[3]; c->stats.sphere_tests = s[4]; c->stats.tri_tests = s[5]; c->stats.rect_tests = s[6];
     c->stats.trace_sections = s[7]; c->stats.trace_lanes = s[8]; c->stats.light_sections = s[9]; c->stats.light_lanes = s[10];
-    for (int i = 0; i < 5; i++) c->stats.section_cycles[i] = s[11 + i];
+    for (int i = 0; i < 16; i++) c->stats.section_cycles[i] = s[16 + i];
     c->stats.kernel_ms = ms;
     c->stats_pending = false;
     return SRT_OK;
@@ -217,9 +217,9 @@ int srt_create(const srt_config* cfg, srt_ctx** out)
     c->device = device;
     bool ok = hipSetDevice(device) == hipSuccess && hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) == hipSuccess &&
               hipEventCreate(&c->ev_begin) == hipSuccess && hipEventCreate(&c->ev_end) == hipSuccess &&
-              hipMalloc((void**)&c->d_stats, 16 * sizeof(unsigned long long)) == hipSuccess &&
+              hipMalloc((void**)&c->d_stats, 32 * sizeof(unsigned long long)) == hipSuccess &&
               hipMalloc((void**)&c->d_counter, sizeof(uint32_t)) == hipSuccess &&
-              hipMemset(c->d_stats, 0, 16 * sizeof(unsigned long long)) == hipSuccess && hipDeviceSynchronize() == hipSuccess;
+              hipMemset(c->d_stats, 0, 32 * sizeof(unsigned long long)) == hipSuccess && hipDeviceSynchronize() == hipSuccess;
     if (!ok) {
         srt_destroy(c);
         return fail(nullptr, SRT_E_HIP, "could not create stream / events / counters on the device");

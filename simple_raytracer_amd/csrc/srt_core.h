@@ -358,7 +358,7 @@ struct LaneStack {
     SRT_HD uint32_t pop() { sp--; return base[sp * STRIDE]; }
 };
 
-template <bool EXACT, bool COUNT, int STRIDE>
+template <bool EXACT, bool COUNT, int STRIDE, bool STACKLESS = false>
 SRT_HD Hit closest_hit(const SceneView& sc, f3 o, f3 d, float t_min, uint32_t* stack_mem, Counters& cnt)
 {
     Hit best;
@@ -396,7 +396,7 @@ SRT_HD Hit closest_hit(const SceneView& sc, f3 o, f3 d, float t_min, uint32_t* s
         return best;
     }
 
-    if (sc.has_bvh) {
+    if (!STACKLESS && sc.has_bvh) {   // STACKLESS: the caller knows that the scene is a flat list or a tiny tree
         const f3 inv = mk3(1.0f / d.x, 1.0f / d.y, 1.0f / d.z);  // CustomRay.dirFrac (RaytracingClasses.cs:16-18)
         LaneStack<STRIDE> st;
         st.base = stack_mem; st.sp = 0;

@@ -43,6 +43,19 @@ __device__ __forceinline__ uint32_t lanes_below(unsigned long long mask)
     return __builtin_amdgcn_mbcnt_hi((uint32_t)(mask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mask, 0u));
 }
 
+// Profiler of the counting builds: shader-clock cycles between consecutive marks, by the part that ended.
+struct ClockProf {
+    unsigned long long cyc[PROF_SLOTS] = {};
+    unsigned long long t = 0ull;
+    __device__ __forceinline__ void start() { t = __builtin_readcyclecounter(); }
+    __device__ __forceinline__ void mark(int i)
+    {
+        unsigned long long now = __builtin_readcyclecounter();
+        cyc[i] += now - t;
+        t = now;
+    }
+};
+
 // SMALL kernels serve scenes that need no traversal stack (a reference tree of a few nodes, walked with the
 // wave-uniform loop, or a handful of surfaces scanned linearly) and whose primitive and material tables fit the
 // limits below.  Their LDS holds those two tables (they are indexed per lane) and the first kLdsFrameLevels
@@ -95,13 +108,13 @@ __global__ void __launch_bounds__(kBlock, SRT_WAVES_PER_SIMD) trace_kernel(Scene
     int phase = LANE_IDLE;
 
     uint32_t sect[4] = {0u, 0u, 0u, 0u};  // counting builds: section executions and the lanes that took part
-    unsigned long long cyc[5] = {0ull, 0ull, 0ull, 0ull, 0ull}, t_mark = 0ull;   // counting builds: shader clock per part
-#define SRT_MARK(i) do { if (COUNT) { unsigned long long t_now = __builtin_readcyclecounter(); cyc[i] += t_now - t_mark; t_mark = t_now; } } while (0)
+    typename std::conditional<COUNT, ClockProf, NoProf>::type prof;   // counting builds: shader clock per part
+#define SRT_MARK(i) prof.mark(i)
     uint32_t next = 0u, end = 0u;  // wave-uniform: the wavefront's private range of items
     bool dry = false;              // wave-uniform: the global counter is exhausted
 
     for (;;) {
-        if (COUNT) t_mark = __builtin_readcyclecounter();
+        if constexpr (COUNT) prof.start();
         const int n_trace = __popcll(__ballot(phase == LANE_TRACE || phase == LANE_RETURN || (phase == LANE_IDLE && !dry)));
         const int n_light = __popcll(__ballot(phase == LANE_LIGHT));
         if (n_trace + n_light == 0) break;
@@ -113,7 +126,7 @@ __global__ void __launch_bounds__(kBlock, SRT_WAVES_PER_SIMD) trace_kernel(Scene
                 phase = lane_return(ln, ret, sc, ra, frames);
                 if (phase == LANE_IDLE) samples[ln.slot] = ret;
             }
-            SRT_MARK(2);
+            SRT_MARK(PROF_RETURN);
             // ---- deal items to idle lanes
             unsigned long long idle = __ballot(phase == LANE_IDLE);
             while (idle != 0ull) {
@@ -134,35 +147,38 @@ __global__ void __launch_bounds__(kBlock, SRT_WAVES_PER_SIMD) trace_kernel(Scene
                 next += want < avail ? want : avail;
                 idle = __ballot(phase == LANE_IDLE);
             }
-            SRT_MARK(0);
+            SRT_MARK(PROF_DEAL);
             // ---- TRACE: closest-hit query of a tree node
             if (COUNT) { sect[0]++; sect[1] += (uint32_t)__popcll(__ballot(phase == LANE_TRACE)); }
             if (phase == LANE_TRACE) {
-                Hit h = closest_hit<EXACT, COUNT, 64>(sc, ln.qo, ln.qd, ln.qtmin, my_stack, cnt);
-                SRT_MARK(1);
+                Hit h = closest_hit<EXACT, COUNT, 64, SMALL>(sc, ln.qo, ln.qd, ln.qtmin, my_stack, cnt);
+                SRT_MARK(PROF_CLOSEST);
                 f3 ret;
                 phase = lane_on_closest(ln, h, ret, sc, ra, frames, unit);
                 if (phase == LANE_IDLE) samples[ln.slot] = ret;
             }
-            SRT_MARK(2);
+            SRT_MARK(PROF_ON_CLOSEST);
         } else {
             // ---- LIGHT: one shadow query per light, then the node's shading
             if (COUNT) { sect[2]++; sect[3] += (uint32_t)n_light; }
             if (phase == LANE_LIGHT) {
                 uint32_t aux[4];
                 rng_call(ln.key, CALL_AUX, aux);
+                SRT_MARK(PROF_AUX);
                 for (uint32_t li = 0; li < sc.n_lights; li++) {
                     f3 o, d;
                     lane_shadow_query(ln, sc, li, aux, unit, o, d);
-                    Hit h = closest_hit<EXACT, COUNT, 64>(sc, o, d, 0.001f, my_stack, cnt);
+                    SRT_MARK(PROF_SHADOW_SETUP);
+                    Hit h = closest_hit<EXACT, COUNT, 64, SMALL>(sc, o, d, 0.001f, my_stack, cnt);
+                    SRT_MARK(PROF_SHADOW_QUERY);
                     lane_on_shadow(ln, h, o, d, sc, li);
+                    SRT_MARK(PROF_LIGHT_EVAL);
                 }
-                SRT_MARK(3);
                 f3 ret;
-                phase = lane_shade(ln, ln.former, ret, sc, ra, frames, aux, unit);
+                phase = lane_shade(ln, ln.former, ret, sc, ra, frames, aux, unit, prof);
                 if (phase == LANE_IDLE) samples[ln.slot] = ret;
             }
-            SRT_MARK(4);
+            SRT_MARK(PROF_CHILD_START);
         }
     }
 
@@ -172,7 +188,7 @@ __global__ void __launch_bounds__(kBlock, SRT_WAVES_PER_SIMD) trace_kernel(Scene
         atomicAdd(&stats[1], v1);
         atomicAdd(&stats[2], v2);
     }
-    if (COUNT) {
+    if constexpr (COUNT) {
         unsigned long long c0 = wave_sum(cnt.box_tests), c1 = wave_sum(cnt.sphere_tests), c2 = wave_sum(cnt.tri_tests), c3 = wave_sum(cnt.rect_tests);
         if (lane == 0u) {
             atomicAdd(&stats[3], c0);
@@ -180,7 +196,7 @@ __global__ void __launch_bounds__(kBlock, SRT_WAVES_PER_SIMD) trace_kernel(Scene
             atomicAdd(&stats[5], c2);
             atomicAdd(&stats[6], c3);
             for (int i = 0; i < 4; i++) atomicAdd(&stats[7 + i], (unsigned long long)sect[i]);
-            for (int i = 0; i < 5; i++) atomicAdd(&stats[11 + i], cyc[i]);
+            for (int i = 0; i < PROF_SLOTS; i++) atomicAdd(&stats[16 + i], prof.cyc[i]);
         }
     }
 }

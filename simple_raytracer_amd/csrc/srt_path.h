@@ -123,6 +123,12 @@ struct HybridFrames {
     }
 };
 
+// Where the time goes: counting builds pass a clock-reading profiler to the per-lane functions, which mark
+// the end of each of their parts; everything else passes NoProf, whose marks compile to nothing.
+struct NoProf { SRT_HD void mark(int) const {} };
+enum { PROF_DEAL = 0, PROF_RETURN, PROF_CLOSEST, PROF_ON_CLOSEST, PROF_AUX, PROF_SHADOW_SETUP, PROF_SHADOW_QUERY, PROF_LIGHT_EVAL,
+       PROF_CHILD_DIRS, PROF_FRESNEL, PROF_CHILD_START, PROF_SLOTS = 16 };
+
 SRT_HD void lane_begin_child(Lane& ln, uint32_t child, f3 origin, f3 unit_dir, int32_t depth)
 {
     ln.key.node = ln.key.node * 4u + child + 1u;
@@ -175,18 +181,20 @@ SRT_HD int lane_return(Lane& ln, f3& ret, const SceneView& sc, const RenderArgs&
 // All lights of the node are in (light_color = lightColor of RaytracingOperations.cs:144): directions of the
 // children, fresnel, and either the first child (LANE_TRACE) or -- when the children would run at depth < 1 -- the
 // node's value in ln.former (LANE_RETURN).  LANE_IDLE with `ret` set ends the sample (lights-only mode).
-template <class FRAMES>
+template <class FRAMES, class PROF = NoProf>
 SRT_HD int lane_shade(Lane& ln, f3 light_color, f3& ret, const SceneView& sc, const RenderArgs& ra, const FRAMES& frames, const uint32_t aux[4],
-                      const float* unit)
+                      const float* unit, PROF&& prof = PROF())
 {
     if ((uint32_t)ra.mode == MODE_LIGHTS) { ret = light_color; return LANE_IDLE; }
     Material m = load_material(sc, ln.mat);
     f3 hemi = random_hemisphere_vector(ln.key, ln.N, unit);
     f3 diffuse_dir = add3(ln.N, hemi);                                                  // :119
+    prof.mark(PROF_CHILD_DIRS);
     f3 rough = ranged_vector_from_word(aux[0], sqrt_rn(m.smoothness), unit);
     f3 refl = reflect3(ln.qd, add3(ln.N, rough));                                       // :128
     float fres = fresnel_term(ln.qd, refl);                                             // :137-140
     float w_refl = (1.0f - m.metalness) * (fres * (m.smoothness * m.smoothness));
+    prof.mark(PROF_FRESNEL);
     int32_t child_depth = ln.depth - 1;
     if (child_depth < 1) {
         // every child returns Vector3.Zero without tracing (:82-83)
@@ -196,6 +204,7 @@ SRT_HD int lane_shade(Lane& ln, f3 light_color, f3& ret, const SceneView& sc, co
         if (m.metalness != 0.0f) acc = add3(acc, mul3(scale3(m.albedo, m.metalness), zero));
         if (m.metalness != 1.0f) acc = add3(acc, scale3(zero, w_refl));
         ln.former = clamp_color(add3(acc, light_color), ra.color_clamp);
+        prof.mark(PROF_CHILD_START);
         return LANE_RETURN;
     }
     Frame f;
@@ -208,6 +217,7 @@ SRT_HD int lane_shade(Lane& ln, f3 light_color, f3& ret, const SceneView& sc, co
     frames.store(ln.level, f);
     ln.level++;
     lane_begin_child(ln, 0u, ln.P, normalize3(diffuse_dir), child_depth);
+    prof.mark(PROF_CHILD_START);
     return LANE_TRACE;
 }
 

@@ -34,6 +34,12 @@ WIDTH, HEIGHT, SPP_PER_GPU, MAX_DEPTH, TILE = 1920, 1080, 16, 8, 32
 PEAK_FP32_TFLOPS = 157.3   # MI355X vector FP32 (= f32 MFMA) peak
 PEAK_HBM_GBS = 8000.0      # MI355X HBM3E peak
 
+# Memory-side bytes per launch of the trace kernel on the N=1 workload, from separate `rocprofv3 --pmc FETCH_SIZE` and
+# `--pmc WRITE_SIZE` passes over this command (tools/pmc_traffic.sh; the counters are in KiB, and FETCH_SIZE is
+# doubled, the correction for gfx950).  They are not re-measured by a normal run: a counter pass needs the profiler.
+# Almost all of it is private-memory traffic of the ray-tree frames below the levels kept in LDS, plus 0.4 GB of samples.
+MEASURED_TRAFFIC_KIB = {"bvhnode": (2687693.8, 11673297.5)}   # (FETCH_SIZE, WRITE_SIZE) of trace_kernel<true,false,true>
+
 # Algorithmic work per event: bytes fetched / FP32 operations (add, sub, mul, div, sqrt, min, max, compare = 1 each)
 # of the reference algorithm, excluding work the GPU legitimately skips.
 EVENT_COST = {                 # (bytes, flops)
@@ -57,15 +63,15 @@ def algorithmic_work(stats, pixels):
 
 def cpu_baseline(width, height, spp, depth):
     """The CPU oracle (a C++ restatement of the reference's algorithm, threaded by row bands like Game1.cs:376-380)
-    timed on this host on a bounded sample: the central quarter of the same frame."""
+    timed on this host on one frame of the same workload (about 20 s on 16 cores)."""
     from oracle import orc   # checker / baseline only
     threads = min(16, os.cpu_count() or 1)
-    win = (width // 4, height // 4, width // 4 + width // 2, height // 4 + height // 2)
+    win = (0, 0, width, height)
     sc, cam = orc.default_scene(), orc.default_camera(width, height)
     _, st = sc.render(cam, width, height, samples=spp, max_depth=depth, seed=1, window=win, threads=threads)
     return {"value": round(st["rays_path"] / st["seconds"] / 1e6, 4), "unit": "Mrays/s", "cores": threads, "kind": "port",
-            "sample": "central %dx%d window of the %dx%d %d-spp depth-%d frame, %d rays in %.2f s" % (
-                win[2] - win[0], win[3] - win[1], width, height, spp, depth, st["rays_path"], st["seconds"])}
+            "sample": "one whole %dx%d %d-spp depth-%d frame (all rows, row bands over %d threads), %d rays in %.2f s" % (
+                width, height, spp, depth, threads, st["rays_path"], st["seconds"])}
 
 
 def main():
@@ -165,7 +171,12 @@ def main():
         roofline = ({"bound": "valu_fp32", "achieved": round(tflops, 3), "peak": PEAK_FP32_TFLOPS, "unit": "TFLOP/s",
                      "frac": round(tflops / PEAK_FP32_TFLOPS, 4)} if valu_bound else
                     {"bound": "hbm", "achieved": round(gbs, 2), "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": round(gbs / PEAK_HBM_GBS, 4)})
-        roofline.update({"traffic": None, "kernel": "trace_kernel", "avg_launch_ms": round(avg_ms, 4),
+        traffic = None
+        if world == 1 and args.world_kind in MEASURED_TRAFFIC_KIB:
+            fetch_kib, write_kib = MEASURED_TRAFFIC_KIB[args.world_kind]
+            traffic = int((2.0 * fetch_kib + write_kib) * 1024)
+        roofline.update({"traffic": traffic, "traffic_source": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command, 2*FETCH+WRITE "
+                         "(profiles/r1_v3_pmc_traffic.txt); constant, not re-measured in this run", "kernel": "trace_kernel", "avg_launch_ms": round(avg_ms, 4),
                          "algorithmic_flops_per_launch": aflops, "algorithmic_bytes_per_launch": abytes,
                          "algorithmic_gbs": round(gbs, 2), "algorithmic_tflops": round(tflops, 3)})
         line = {

@@ -23,6 +23,9 @@
 
 namespace srt {
 
+#ifndef SRT_WAVES_PER_SIMD_BIG
+#define SRT_WAVES_PER_SIMD_BIG 3
+#endif
 #ifndef SRT_WAVES_PER_SIMD
 #define SRT_WAVES_PER_SIMD 3   // occupancy the register allocator is asked to make room for (measured: 2 -> 25.7 ms, 3 -> 21.1 ms, 4 -> 22.7 ms)
 #endif
@@ -71,7 +74,7 @@ __device__ __forceinline__ void copy_words(q4* dst, const q4* src, uint32_t n)
 }
 
 template <bool EXACT, bool COUNT, bool SMALL>
-__global__ void __launch_bounds__(kBlock, SRT_WAVES_PER_SIMD) trace_kernel(SceneView gsc, RenderArgs ra, f3* __restrict__ samples,
+__global__ void __launch_bounds__(kBlock, SMALL ? SRT_WAVES_PER_SIMD : SRT_WAVES_PER_SIMD_BIG) trace_kernel(SceneView gsc, RenderArgs ra, f3* __restrict__ samples,
                                                        unsigned long long* __restrict__ stats, uint32_t* __restrict__ work_counter,
                                                        int trace_vote, uint32_t chunk)
 {

@@ -39,6 +39,10 @@ def main():
         t = time.time()
         r.set_scene(world, lights, cam, world_kind=srt.WORLD_SURFACELIST)
         commit_s = time.time() - t
+        if "--once" in sys.argv:      # one render and nothing else: the run that counter passes profile
+            r.render(W, H, samples=spp, max_depth=depth, seed=1)
+            print(json.dumps({"config": name, "spp": spp, "kernel_ms": round(r.stats()["kernel_ms"], 3)}), flush=True)
+            continue
         r.render(W, H, samples=1, max_depth=depth, seed=1)   # warm-up
         img = r.render(W, H, samples=spp, max_depth=depth, seed=1)
         st = r.stats()
@@ -54,6 +58,12 @@ def main():
                 "algorithmic_GBs": round((cst["box_tests"] * 32 + cst["tri_tests"] * 36 + cst["sphere_tests"] * 16 + cst["hit_nodes"] * 72
                                           + cst["rays_shadow"] * 28) / st["kernel_ms"] / 1e6, 1),
                 "nonblack_fraction": round(float(((img & 0xFFFFFF) != 0).mean()), 3)}
+        names = ["deal", "return", "closest", "on_closest", "aux", "shadow_setup", "shadow_query", "light_eval", "child_dirs", "fresnel",
+                 "child_start"]
+        tot = float(sum(cst["section_cycles"])) or 1.0
+        line["cycle_share"] = {n: round(c / tot, 3) for n, c in zip(names, cst["section_cycles"])}
+        line["lanes_per_trace_section"] = round(cst["trace_lanes"] / max(1, cst["trace_sections"]), 1)
+        line["lanes_per_light_section"] = round(cst["light_lanes"] / max(1, cst["light_sections"]), 1)
         if "--cpu" in sys.argv:
             from oracle import orc   # CPU baseline only
             import helpers

@@ -58,7 +58,9 @@ enum {
     SRT_MODE_COLOR = 0,      /* RayOperations.GetRayColor        RaytracingOperations.cs:75-195 */
     SRT_MODE_NORMAL = 1,     /* RayOperations.GetRayNormalColor  RaytracingOperations.cs:11-21 */
     SRT_MODE_DEPTH = 2,      /* RayOperations.GetRayDepthColor   RaytracingOperations.cs:24-35 */
-    SRT_MODE_LIGHTS = 3      /* RayOperations.GetLights          RaytracingOperations.cs:197-205 */
+    SRT_MODE_LIGHTS = 3,     /* RayOperations.GetLights          RaytracingOperations.cs:197-205 */
+    SRT_MODE_DIFFUSE = 4,    /* RayOperations.GetRayColorDiffuse    RaytracingOperations.cs:38-54, depth = max_depth */
+    SRT_MODE_REFLECTION = 5  /* RayOperations.GetRayColorReflection RaytracingOperations.cs:57-73, depth = max_depth */
 };
 
 /* Output layout of a render. */

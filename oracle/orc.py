@@ -14,7 +14,7 @@ _LIB_PATH = os.path.join(_HERE, "liborc.so")
 
 WORLD_BVHNODE = 0
 WORLD_SURFACELIST = 1
-MODE_COLOR, MODE_NORMAL, MODE_DEPTH, MODE_LIGHTS = 0, 1, 2, 3
+MODE_COLOR, MODE_NORMAL, MODE_DEPTH, MODE_LIGHTS, MODE_DIFFUSE, MODE_REFLECTION = 0, 1, 2, 3, 4, 5
 
 
 class Material(C.Structure):
@@ -98,6 +98,8 @@ def lib():
         L.orc_angle_between.argtypes = [F3, F3]
         L.orc_get_lights.argtypes = [C.c_void_p, C.c_int, F3, F3] + [C.c_uint32] * 4 + [F3]
         L.orc_get_ray_color.argtypes = [C.c_void_p, C.c_int, F3, F3, C.c_int, C.c_float] + [C.c_uint32] * 3 + [F3]
+        L.orc_get_debug_color.argtypes = [C.c_void_p, C.c_int, C.c_int, F3, F3, C.c_int] + [C.c_uint32] * 3 + [F3]
+        L.orc_get_debug_color.restype = None
         _lib = L
     return _lib
 

@@ -204,6 +204,8 @@ inline Vec ReturnRandomUnitSphereVector(const RngKey& k)
     }
     return p;
 }
+// MiscFunctions.cs:36-39
+inline Vec ReturnRandomNormalizedUnitSphereVector(const RngKey& k) { return Normalize(ReturnRandomUnitSphereVector(k)); }
 // MiscFunctions.cs:41-48
 inline Vec ReturnHemisphereRandomVector(const RngKey& k, Vec normal)
 {
@@ -768,6 +770,41 @@ Vec GetRayDepthColor(const CustomRay& ray, const Surface* world)
     return t * V(0, 0, 0);
 }
 
+// The child of a node in the single-child recursions below: the same id rule as GetRayColor's diffuse child.
+inline RngKey FirstChild(RngKey key) { key.node = key.node * 4u + 1u; return key; }
+
+// :38-54
+Vec GetRayColorDiffuse(const CustomRay& ray, const Surface* world, RngKey key, int depth)
+{
+    hitRecord record;
+    if (depth < 1) return V(0, 0, 0);
+    C().rays_path++;
+    if (world->hit(ray, 0.001f, kInf, record)) {
+        C().hit_nodes++;
+        Vec target = record.point + record.normal + ReturnRandomNormalizedUnitSphereVector(key);
+        return 0.5f * (GetRayColorDiffuse(CustomRay(record.point, target - record.point), world, FirstChild(key), depth - 1));
+    }
+    Vec direction = Normalize(ray.direction);
+    float t = 0.5f * (direction.Y + 1);
+    return t * V(0.85f, 0.75f, 1.f) + (1 - t) * V(1, 1, 1);
+}
+
+// :57-73
+Vec GetRayColorReflection(const CustomRay& ray, const Surface* world, RngKey key, int depth)
+{
+    hitRecord record;
+    if (depth < 1) return V(0, 0, 0);
+    C().rays_path++;
+    if (world->hit(ray, 0.001f, kInf, record)) {
+        C().hit_nodes++;
+        Vec target = record.point + Reflect(ray.direction, record.normal);
+        return 0.5f * (GetRayColorReflection(CustomRay(record.point, target - record.point), world, FirstChild(key), depth - 1));
+    }
+    Vec direction = Normalize(ray.direction);
+    float t = 0.5f * (direction.Y + 1);
+    return t * V(0.85f, 0.75f, 1.f) + (1 - t) * V(1, 1, 1);
+}
+
 }  // namespace
 
 // ---------------------------------------------------------------------------------------
@@ -825,6 +862,8 @@ void renderBlock(const orc_scene* s, const Surface* world, const orc_camera* cam
                     case ORC_MODE_NORMAL: c = GetRayNormalColor(ray, world); break;
                     case ORC_MODE_DEPTH: c = GetRayDepthColor(ray, world); break;
                     case ORC_MODE_LIGHTS: c = GetLights(ray, world, key, &s->lights); break;
+                    case ORC_MODE_DIFFUSE: c = GetRayColorDiffuse(ray, world, key, p->max_depth); break;
+                    case ORC_MODE_REFLECTION: c = GetRayColorReflection(ray, world, key, p->max_depth); break;
                     default: c = GetRayColor(ray, world, key, p->max_depth, &s->lights, p->color_clamp, &nodes); break;
                 }
                 vectorRayColor = vectorRayColor + c / (float)samples;
@@ -1100,6 +1139,19 @@ void orc_get_ray_color(const orc_scene* s, int world_kind, const float o[3], con
     if (!world) return;
     RngKey k{seed, pixel, sample, 1};
     Vec c = GetRayColor(CustomRay(A3(o), A3(d)), world, k, depth, &s->lights, clamp, nullptr);
+    rgb[0] = c.X; rgb[1] = c.Y; rgb[2] = c.Z;
+}
+
+// mode: ORC_MODE_DIFFUSE or ORC_MODE_REFLECTION
+void orc_get_debug_color(const orc_scene* s, int world_kind, int mode, const float o[3], const float d[3], int depth, uint32_t seed,
+                         uint32_t pixel, uint32_t sample, float rgb[3])
+{
+    const Surface* world = pickWorld(s, world_kind);
+    rgb[0] = rgb[1] = rgb[2] = 0;
+    if (!world) return;
+    RngKey k{seed, pixel, sample, 1};
+    CustomRay ray(A3(o), A3(d));
+    Vec c = mode == ORC_MODE_DIFFUSE ? GetRayColorDiffuse(ray, world, k, depth) : GetRayColorReflection(ray, world, k, depth);
     rgb[0] = c.X; rgb[1] = c.Y; rgb[2] = c.Z;
 }
 

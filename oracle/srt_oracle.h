@@ -29,7 +29,7 @@ typedef struct { float position[3]; float brightness; float color[3]; } orc_ligh
 typedef struct { float position[3]; float lower_left[3]; float horizontal[3]; float vertical[3]; } orc_camera; /* RaytracingClasses.cs:32-64 */
 
 enum { ORC_WORLD_BVHNODE = 0, ORC_WORLD_SURFACELIST = 1 };
-enum { ORC_MODE_COLOR = 0, ORC_MODE_NORMAL = 1, ORC_MODE_DEPTH = 2, ORC_MODE_LIGHTS = 3 };
+enum { ORC_MODE_COLOR = 0, ORC_MODE_NORMAL = 1, ORC_MODE_DEPTH = 2, ORC_MODE_LIGHTS = 3, ORC_MODE_DIFFUSE = 4, ORC_MODE_REFLECTION = 5 };
 
 typedef struct {
     int32_t  width, height;      /* full image size (globalWidth/globalHeight, Game1.cs:283-284) */
@@ -103,6 +103,8 @@ int orc_get_lights(const orc_scene*, int world_kind, const float o[3], const flo
 /* One GetRayColor call from an arbitrary ray (node id 1 = a primary ray). */
 void orc_get_ray_color(const orc_scene*, int world_kind, const float o[3], const float d[3], int depth, float clamp,
                        uint32_t seed, uint32_t pixel, uint32_t sample, float rgb[3]);
+void orc_get_debug_color(const orc_scene*, int world_kind, int mode, const float o[3], const float d[3], int depth, uint32_t seed,
+                         uint32_t pixel, uint32_t sample, float rgb[3]);   /* GetRayColorDiffuse / GetRayColorReflection */
 
 #ifdef __cplusplus
 }

@@ -4,7 +4,7 @@ The compute path is libsrt.so (hand-written HIP kernels behind the C ABI of incl
 is the host side: scene classes mirroring the reference's, the Game1 scene literals, and the render driver.
 """
 from . import _native
-from ._native import (LAYOUT_FRAME, LAYOUT_TILES, MODE_COLOR, MODE_DEPTH, MODE_LIGHTS, MODE_NORMAL, WORLD_BVHNODE,
+from ._native import (LAYOUT_FRAME, LAYOUT_TILES, MODE_COLOR, MODE_DEPTH, MODE_DIFFUSE, MODE_LIGHTS, MODE_NORMAL, MODE_REFLECTION, WORLD_BVHNODE,
                       WORLD_SURFACELIST, SrtError)
 from .raytracing import (Camera, Light, LightList, Material, PointLight, RectAxis, Sphere, Surface, SurfaceList, Tri, TriMesh,
                          Vert)
@@ -12,4 +12,4 @@ from .renderer import Renderer, rgba_to_rgb8
 
 __all__ = ["Camera", "Light", "LightList", "Material", "PointLight", "RectAxis", "Sphere", "Surface", "SurfaceList", "Tri",
            "TriMesh", "Vert", "Renderer", "rgba_to_rgb8", "SrtError", "WORLD_BVHNODE", "WORLD_SURFACELIST", "MODE_COLOR",
-           "MODE_NORMAL", "MODE_DEPTH", "MODE_LIGHTS", "LAYOUT_FRAME", "LAYOUT_TILES"]
+           "MODE_NORMAL", "MODE_DEPTH", "MODE_LIGHTS", "MODE_DIFFUSE", "MODE_REFLECTION", "LAYOUT_FRAME", "LAYOUT_TILES"]

@@ -12,7 +12,7 @@ DEFAULT_LIBRARY = os.environ.get("SRT_LIBRARY") or os.path.join(_HERE, "csrc", "
 
 OK, E_INVALID, E_NO_DEVICE, E_HIP, E_STATE, E_REFERENCE, E_LIMIT = 0, -1, -2, -3, -4, -5, -6
 WORLD_BVHNODE, WORLD_SURFACELIST = 0, 1
-MODE_COLOR, MODE_NORMAL, MODE_DEPTH, MODE_LIGHTS = 0, 1, 2, 3
+MODE_COLOR, MODE_NORMAL, MODE_DEPTH, MODE_LIGHTS, MODE_DIFFUSE, MODE_REFLECTION = 0, 1, 2, 3, 4, 5
 LAYOUT_FRAME, LAYOUT_TILES = 0, 1
 MAX_DEPTH = 16
 

@@ -158,7 +158,7 @@ SRT_HD uint32_t light_word(const RngKey& k, const uint32_t aux[4], uint32_t l)
 }
 // RandomVector.ReturnHemisphereRandomVector over ReturnRandomUnitSphereVector (MiscFunctions.cs:26-48).
 // The rejection loop is bounded at MAX_REJECTION_TRIES (probability of getting there: (1 - pi/6)^64 ~ 2e-21).
-SRT_HD f3 random_hemisphere_vector(const RngKey& k, f3 normal, const float* unit)
+SRT_HD f3 random_unit_sphere_vector(const RngKey& k, const float* unit)
 {
     f3 p = mk3(0.0f, 0.0f, 0.0f);
     bool found = false;
@@ -170,6 +170,11 @@ SRT_HD f3 random_hemisphere_vector(const RngKey& k, f3 normal, const float* unit
             found = !(lensq3(p) >= 1.0f);
         }
     }
+    return p;
+}
+SRT_HD f3 random_hemisphere_vector(const RngKey& k, f3 normal, const float* unit)
+{
+    f3 p = random_unit_sphere_vector(k, unit);
     if (dot3(p, normal) > 0.0f) return p;
     return neg3(p);
 }
@@ -622,7 +627,7 @@ struct Frame {
     uint32_t meta; // material | child depth << 24
 };
 
-enum : uint32_t { MODE_COLOR = 0u, MODE_NORMAL = 1u, MODE_DEPTH = 2u, MODE_LIGHTS = 3u };
+enum : uint32_t { MODE_COLOR = 0u, MODE_NORMAL = 1u, MODE_DEPTH = 2u, MODE_LIGHTS = 3u, MODE_DIFFUSE = 4u, MODE_REFLECTION = 5u };
 
 // Maps a pixel slot of this rank to its pixel.  Slots enumerate this rank's tiles (tile t belongs to
 // rank t % world_size), and inside a tile 8x8 blocks, so that 64 consecutive slots are an 8x8

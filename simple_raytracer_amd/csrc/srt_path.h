@@ -66,7 +66,8 @@ SRT_HD bool item_start(Lane& ln, const RenderArgs& ra, uint32_t item, const floa
                  ((cm.lower_left.z + u * cm.horizontal.z) + v * cm.vertical.z) - cm.position.z);
     ln.qo = cm.position;
     ln.qd = normalize3(dir);
-    ln.qtmin = ((uint32_t)ra.mode == MODE_NORMAL || (uint32_t)ra.mode == MODE_DEPTH) ? 0.0f : 0.01f;
+    const uint32_t mode = (uint32_t)ra.mode;   // t_min of world.hit: 0 (normal, depth), 0.001 (diffuse, reflection), 0.01
+    ln.qtmin = (mode == MODE_NORMAL || mode == MODE_DEPTH) ? 0.0f : ((mode == MODE_DIFFUSE || mode == MODE_REFLECTION) ? 0.001f : 0.01f);
     ln.key.node = 1u;
     ln.depth = ra.max_depth;
     ln.level = 0;
@@ -244,6 +245,28 @@ SRT_HD int lane_on_closest(Lane& ln, const Hit& h, f3& ret, const SceneView& sc,
             else ret = mk3(t * 0.0f, t * 0.0f, t * 0.0f);
         }
         return LANE_IDLE;
+    }
+    if (mode == MODE_DIFFUSE || mode == MODE_REFLECTION) {
+        // GetRayColorDiffuse / GetRayColorReflection (RaytracingOperations.cs:38-73): one child per hit, the miss
+        // colour halved once per level on the way back; ln.level counts the levels.
+        if (ln.depth < 1) { ret = mk3(0.0f, 0.0f, 0.0f); return LANE_IDLE; }
+        ln.rays_path++;
+        if (h.prim == NO_PRIM) {
+            f3 dn = normalize3(ln.qd);
+            float t = 0.5f * (dn.y + 1.0f);
+            ret = mk3(t * 0.85f + (1.0f - t) * 1.0f, t * 0.75f + (1.0f - t) * 1.0f, t * 1.0f + (1.0f - t) * 1.0f);
+            for (int32_t i = 0; i < ln.level; i++) ret = mk3(0.5f * ret.x, 0.5f * ret.y, 0.5f * ret.z);
+            return LANE_IDLE;
+        }
+        ln.hit_nodes++;
+        HitRecord r = resolve_hit(sc, h, ln.qo, ln.qd);
+        f3 target;
+        if (mode == MODE_DIFFUSE) target = add3(add3(r.point, r.normal), normalize3(random_unit_sphere_vector(ln.key, unit)));
+        else target = add3(r.point, reflect3(ln.qd, r.normal));
+        ln.level++;
+        lane_begin_child(ln, 0u, r.point, normalize3(sub3(target, r.point)), ln.depth - 1);
+        ln.qtmin = 0.001f;
+        return LANE_TRACE;
     }
     if (mode == MODE_LIGHTS) {
         // GetLights on the primary ray (RaytracingOperations.cs:197-205)

@@ -445,7 +445,7 @@ static int check_params(const srt_render_params* p, int& tw, int& th, int& world
     if (p->max_depth < 0 || p->max_depth > SRT_MAX_DEPTH) return fail(SRT_E_LIMIT, "max_depth must be within 0..SRT_MAX_DEPTH");
     if (p->color_clamp != p->color_clamp) return fail(SRT_E_INVALID, "color_clamp is NaN");
     if (p->color_clamp < 0) return fail(SRT_E_REFERENCE, "Math.Clamp(x, 0, clamp) throws ArgumentException when clamp < 0");
-    if (p->mode < SRT_MODE_COLOR || p->mode > SRT_MODE_LIGHTS) return fail(SRT_E_INVALID, "unknown mode");
+    if (p->mode < SRT_MODE_COLOR || p->mode > SRT_MODE_REFLECTION) return fail(SRT_E_INVALID, "unknown mode");
     if (p->layout != SRT_LAYOUT_FRAME && p->layout != SRT_LAYOUT_TILES) return fail(SRT_E_INVALID, "unknown layout");
     tw = p->tile_w ? p->tile_w : 32;
     th = p->tile_h ? p->tile_h : 32;

@@ -14,12 +14,17 @@ import simple_raytracer_amd as srt
 
 BVH, LIST = srt.WORLD_BVHNODE, srt.WORLD_SURFACELIST
 COLOR, NORMAL, DEPTH, LIGHTS = srt.MODE_COLOR, srt.MODE_NORMAL, srt.MODE_DEPTH, srt.MODE_LIGHTS
+DIFFUSE, REFLECTION = srt.MODE_DIFFUSE, srt.MODE_REFLECTION
 
 # (name, spec factory, width, height, samples, max_depth, mode, world_kind, seed)
 CASES = [
     ("default-normal", helpers.default_spec, 160, 90, 1, 4, NORMAL, BVH, 1),
     ("default-depth", helpers.default_spec, 160, 90, 1, 4, DEPTH, BVH, 1),
     ("default-lights", helpers.default_spec, 160, 90, 2, 4, LIGHTS, BVH, 1),
+    ("default-diffuse-mode", helpers.default_spec, 160, 90, 2, 6, DIFFUSE, BVH, 1),
+    ("default-reflection-mode", helpers.default_spec, 160, 90, 1, 6, REFLECTION, BVH, 1),
+    ("mesh-diffuse-mode-list", lambda: helpers.mesh_spec(n=8), 96, 54, 2, 16, DIFFUSE, LIST, 4),
+    ("default-reflection-depth0", helpers.default_spec, 32, 18, 1, 0, REFLECTION, BVH, 1),
     ("default-1spp-bvhnode", helpers.default_spec, 160, 90, 1, 4, COLOR, BVH, 1),
     ("default-1spp-list", helpers.default_spec, 160, 90, 1, 4, COLOR, LIST, 1),
     ("default-4spp-depth8", helpers.default_spec, 128, 72, 4, 8, COLOR, BVH, 12345),

@@ -160,6 +160,31 @@ def test_emissive_sphere_is_depth_one(oracle):
     assert list(out) == [0.0, 0.0, 0.0]   # depth < 1 returns black without tracing
 
 
+def test_diffuse_and_reflection_debug_modes(oracle):
+    # RaytracingOperations.cs:38-73.  One sphere of radius 1 at (0, 0, -5), no lights.
+    mats = [oracle.material((0.5, 0.5, 0.5), 0.0, 0.5, (0, 0, 0))]
+    sc = oracle.Scene(mats, spheres=[oracle.Sphere(oracle.f3((0, 0, -5)), 1.0, 0)])
+    L = oracle.lib()
+    out = (C.c_float * 3)()
+    o = oracle.f3((0, 0, 0))
+    for mode in (oracle.MODE_DIFFUSE, oracle.MODE_REFLECTION):
+        # a ray straight up misses: t = 0.5 (1 + 1) = 1 => (0.85, 0.75, 1) exactly
+        L.orc_get_debug_color(sc.handle, oracle.WORLD_SURFACELIST, mode, o, oracle.f3((0, 1, 0)), 5, 1, 0, 0, out)
+        assert list(out) == [np.float32(0.85), np.float32(0.75), 1.0]
+        # depth 1: the hit's only child runs at depth 0 and returns zero; depth 0 returns zero at once
+        for depth in (1, 0):
+            L.orc_get_debug_color(sc.handle, oracle.WORLD_SURFACELIST, mode, o, oracle.f3((0, 0, -1)), depth, 1, 0, 0, out)
+            assert list(out) == [0.0, 0.0, 0.0]
+    # reflection, head-on: hit at (0, 0, -4), normal (0, 0, 1), reflected direction (0, 0, 1) leaves the scene with
+    # t = 0.5 (0 + 1) = 0.5 => 0.5 * (0.5 (0.85, 0.75, 1) + 0.5 (1, 1, 1)) = (0.4625, 0.4375, 0.5)
+    L.orc_get_debug_color(sc.handle, oracle.WORLD_SURFACELIST, oracle.MODE_REFLECTION, o, oracle.f3((0, 0, -1)), 3, 1, 0, 0, out)
+    assert np.allclose(list(out), [0.4625, 0.4375, 0.5], rtol=0, atol=1e-7)
+    # diffuse, head-on: the child direction is normal + a unit vector, so it leaves through the hemisphere of the normal
+    # (z >= 0 up to rounding) and misses: 0.5 * sky, each channel within the sky's range halved
+    L.orc_get_debug_color(sc.handle, oracle.WORLD_SURFACELIST, oracle.MODE_DIFFUSE, o, oracle.f3((0, 0, -1)), 3, 1, 0, 0, out)
+    assert 0.425 <= out[0] <= 0.5 and 0.375 <= out[1] <= 0.5 and out[2] == 0.5
+
+
 def _pcg4d(x, y, z, w):
     M = 0xFFFFFFFF
     x, y, z, w = [(v * 1664525 + 1013904223) & M for v in (x, y, z, w)]

@@ -402,6 +402,11 @@ SRT_HD Hit closest_hit(const SceneView& sc, f3 o, f3 d, float t_min, uint32_t* s
     }
 
     if (!STACKLESS && sc.has_bvh) {   // STACKLESS: the caller knows that the scene is a flat list or a tiny tree
+        // Two loops inside one: descend through inner nodes until the lane holds a leaf (or nothing), then test the
+        // leaf's primitives.  The lanes of a wavefront wait for each other at the end of the descent, so that they
+        // run the (expensive) primitive tests together instead of every lane dragging the others through both kinds
+        // of step on every iteration.
+        const uint32_t kNone = 0xFFFFFFFFu;   // has the leaf bit: ends the descent like a leaf does
         const f3 inv = mk3(1.0f / d.x, 1.0f / d.y, 1.0f / d.z);  // CustomRay.dirFrac (RaytracingClasses.cs:16-18)
         LaneStack<STRIDE> st;
         st.base = stack_mem; st.sp = 0;
@@ -409,39 +414,38 @@ SRT_HD Hit closest_hit(const SceneView& sc, f3 o, f3 d, float t_min, uint32_t* s
         if (COUNT) cnt.box_tests++;
         float tn;
         bool root_hit = EXACT ? box_hit_reference(r0, r1, o, inv) : box_hit_padded(r0, r1, o, inv, best.t, tn);
-        uint32_t cur = fbits(r0.w);
-        bool live = root_hit;
-        while (live) {
-            if (cur & DESC_LEAF) {
+        uint32_t cur = root_hit ? fbits(r0.w) : kNone;
+        while (cur != kNone) {
+            while (!(cur & DESC_LEAF)) {
+                // inner node: its two children are adjacent
+                q4 l0 = sc.nodes[2 * cur], l1 = sc.nodes[2 * cur + 1];
+                q4 h0 = sc.nodes[2 * cur + 2], h1 = sc.nodes[2 * cur + 3];
+                if (COUNT) cnt.box_tests += 2;
+                uint32_t dl = fbits(l0.w), dr = fbits(h0.w);
+                bool hl, hr;
+                if (EXACT) {
+                    hl = box_hit_reference(l0, l1, o, inv);
+                    hr = box_hit_reference(h0, h1, o, inv);
+                    if (hl) { if (hr) st.push(dr); cur = dl; }
+                    else if (hr) cur = dr;
+                    else cur = st.sp == 0 ? kNone : st.pop();
+                } else {
+                    float tl, tr;
+                    hl = box_hit_padded(l0, l1, o, inv, best.t, tl);
+                    hr = box_hit_padded(h0, h1, o, inv, best.t, tr);
+                    if (hl & hr) {
+                        bool left_first = !(tr < tl);
+                        st.push(left_first ? dr : dl);
+                        cur = left_first ? dl : dr;
+                    } else if (hl) cur = dl;
+                    else if (hr) cur = dr;
+                    else cur = st.sp == 0 ? kNone : st.pop();
+                }
+            }
+            if (cur != kNone) {
                 uint32_t first = cur & 0x07FFFFFFu, count = ((cur >> 27) & 15u) + 1u;
                 for (uint32_t i = 0; i < count; i++) test_prim<COUNT>(sc, first + i, o, d, a, t_min, best, cnt);
-                if (st.sp == 0) break;
-                cur = st.pop();
-                continue;
-            }
-            // inner node: its two children are adjacent
-            q4 l0 = sc.nodes[2 * cur], l1 = sc.nodes[2 * cur + 1];
-            q4 h0 = sc.nodes[2 * cur + 2], h1 = sc.nodes[2 * cur + 3];
-            if (COUNT) cnt.box_tests += 2;
-            uint32_t dl = fbits(l0.w), dr = fbits(h0.w);
-            bool hl, hr;
-            if (EXACT) {
-                hl = box_hit_reference(l0, l1, o, inv);
-                hr = box_hit_reference(h0, h1, o, inv);
-                if (hl) { if (hr) st.push(dr); cur = dl; }
-                else if (hr) cur = dr;
-                else { if (st.sp == 0) break; cur = st.pop(); }
-            } else {
-                float tl, tr;
-                hl = box_hit_padded(l0, l1, o, inv, best.t, tl);
-                hr = box_hit_padded(h0, h1, o, inv, best.t, tr);
-                if (hl & hr) {
-                    bool left_first = !(tr < tl);
-                    st.push(left_first ? dr : dl);
-                    cur = left_first ? dl : dr;
-                } else if (hl) cur = dl;
-                else if (hr) cur = dr;
-                else { if (st.sp == 0) break; cur = st.pop(); }
+                cur = st.sp == 0 ? kNone : st.pop();
             }
         }
     }

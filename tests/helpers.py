@@ -181,3 +181,20 @@ def psnr(a, b):
     db = orc.rgba_to_rgb8(np.asarray(b)).astype(np.float64)
     mse = np.mean((da - db) ** 2)
     return float("inf") if mse == 0 else 10.0 * np.log10(255.0 ** 2 / mse)
+
+
+def oracle_scene_from_world(orc, world, lights):
+    """The oracle's scene for a host-side world (SurfaceList of spheres, rects and triangle meshes) and LightList."""
+    flat = world.flatten()
+    mats = [orc.material(m.albedo, m.metalness, m.smoothness, m.emission) for m in flat["materials"]]
+    tris = None
+    if len(flat["tri_pos"]):
+        tris = orc.tris_from_arrays(flat["tri_pos"], flat["tri_nrm"], 0)
+        tris["material"] = flat["tri_mat"]
+    sph = [orc.Sphere(orc.f3(s[:3]), float(s[3]), int(m)) for s, m in zip(flat["spheres"], flat["sphere_mat"])]
+    ol = [orc.point_light(l.position, l.brightness, None) for l in lights.lights]
+    return orc.Scene(mats, spheres=sph, tris=tris, lights=ol)
+
+
+def oracle_camera_from(orc, cam):
+    return orc.Camera(orc.f3(cam.position), orc.f3(cam.lowerLeftCorner), orc.f3(cam.horizontal), orc.f3(cam.vertical))

@@ -6,6 +6,7 @@ import numpy as np
 import pytest
 
 import helpers
+import mesh_cases
 import parity_cases
 import simple_raytracer_amd as srt
 from golden.make_golden import GOLDEN
@@ -38,6 +39,17 @@ def test_gpu_reproduces_golden(gpu, name):
     if mode == srt.MODE_COLOR:
         st = gpu.stats()
         assert [st["rays_path"], st["rays_shadow"], st["hit_nodes"]] == g["counts"].tolist()
+
+
+@pytest.mark.parametrize("case", mesh_cases.CASES, ids=[c[0] for c in mesh_cases.CASES])
+def test_gpu_sah_tree_matches_linear_scan(gpu, oracle, case):
+    """SRT_WORLD_SURFACELIST on meshes made from the reference's models: the library's own SAH tree against the
+    oracle's linear SurfaceList.hit scan."""
+    lsb, npx, st, ost = mesh_cases.run(gpu, oracle, case, counted=True)
+    assert lsb <= 1, "%s: %d LSB over %d pixels" % (case[0], lsb, npx)
+    for k in ("rays_path", "rays_shadow", "hit_nodes"):
+        assert st[k] == ost[k], (case[0], k)
+    assert st["bvh_nodes"] > 100 and st["box_tests"] > 0
 
 
 def test_gpu_tile_layout(gpu, oracle):

@@ -42,3 +42,15 @@ def test_empty_world_renders_sky(emu, oracle):
     ref, _ = spec.oracle_scene().render(spec.oracle_camera(32, 18), 32, 18, samples=1, max_depth=4,
                                         world_kind=oracle.WORLD_SURFACELIST)
     assert (img == ref).all()
+
+
+import mesh_cases  # noqa: E402
+
+
+@pytest.mark.parametrize("case", mesh_cases.CASES, ids=[c[0] for c in mesh_cases.CASES])
+def test_sah_tree_matches_linear_scan(emu, oracle, case):
+    lsb, npx, st, ost = mesh_cases.run(emu, oracle, case)
+    assert (lsb, npx) == (0, 0)
+    for k in ("rays_path", "rays_shadow", "hit_nodes"):
+        assert st[k] == ost[k], (case[0], k)
+    assert st["bvh_nodes"] > 100 and st["box_tests"] > 0

@@ -453,6 +453,85 @@ SRT_HD Hit closest_hit(const SceneView& sc, f3 o, f3 d, float t_min, uint32_t* s
 }
 
 // ------------------------------------------------------------------------------------------
+// The same query in resumable form, for kernels that interleave the traversals of many lanes with other work: the
+// state of a traversal is (ray direction, best hit so far, current node, stack height) plus the lane's stack column.
+//   trav_begin   the linearly scanned primitives and the root box; scenes without a stack traversal (flat lists,
+//                tiny reference trees) are answered completely here.
+//   trav_run     at most `rounds` times: descend at most `steps` inner nodes, then test the leaf reached (if one was).
+// A traversal is finished when tr.cur == TRAV_NONE; any split into rounds gives the result of closest_hit().
+// ------------------------------------------------------------------------------------------
+enum : uint32_t { TRAV_NONE = 0xFFFFFFFFu, TRAV_NEW = 0xFFFFFFFEu };   // both carry the leaf bit; no real leaf has 16 primitives
+struct Trav { f3 d; Hit best; uint32_t cur; int32_t sp; };
+
+template <bool EXACT, bool COUNT, int STRIDE>
+SRT_HD void trav_begin(const SceneView& sc, f3 o, float t_min, Trav& tr, uint32_t* stack_mem, Counters& cnt)
+{
+    tr.sp = 0;
+    if (sc.has_bvh == 0u || (EXACT && sc.n_tiny != 0u)) {
+        tr.best = closest_hit<EXACT, COUNT, STRIDE, true>(sc, o, tr.d, t_min, stack_mem, cnt);
+        tr.cur = TRAV_NONE;
+        return;
+    }
+    Hit best;
+    best.t = INFINITY; best.prim = NO_PRIM; best.u = 0.0f; best.v = 0.0f; best.order = 0u;
+    const f3 d = tr.d;
+    const float a = lensq3(d);
+    for (uint32_t i = 0; i < sc.list_count; i++) test_prim<COUNT>(sc, sc.list_first + i, o, d, a, t_min, best, cnt);
+    const f3 inv = mk3(1.0f / d.x, 1.0f / d.y, 1.0f / d.z);
+    q4 r0 = sc.nodes[0], r1 = sc.nodes[1];
+    if (COUNT) cnt.box_tests++;
+    float tn;
+    bool root_hit = EXACT ? box_hit_reference(r0, r1, o, inv) : box_hit_padded(r0, r1, o, inv, best.t, tn);
+    tr.cur = root_hit ? fbits(r0.w) : (uint32_t)TRAV_NONE;
+    tr.best = best;
+}
+
+template <bool EXACT, bool COUNT, int STRIDE>
+SRT_HD void trav_run(const SceneView& sc, f3 o, float t_min, Trav& tr, uint32_t* stack_mem, Counters& cnt, int rounds, int steps)
+{
+    const f3 d = tr.d;
+    const float a = lensq3(d);
+    const f3 inv = mk3(1.0f / d.x, 1.0f / d.y, 1.0f / d.z);  // CustomRay.dirFrac (RaytracingClasses.cs:16-18)
+    LaneStack<STRIDE> st;
+    st.base = stack_mem; st.sp = tr.sp;
+    Hit best = tr.best;
+    uint32_t cur = tr.cur;
+    for (int r = 0; r < rounds && cur != TRAV_NONE; r++) {
+        for (int s = 0; s < steps && !(cur & DESC_LEAF); s++) {
+            q4 l0 = sc.nodes[2 * cur], l1 = sc.nodes[2 * cur + 1];
+            q4 h0 = sc.nodes[2 * cur + 2], h1 = sc.nodes[2 * cur + 3];
+            if (COUNT) cnt.box_tests += 2;
+            uint32_t dl = fbits(l0.w), dr = fbits(h0.w);
+            bool hl, hr;
+            if (EXACT) {
+                hl = box_hit_reference(l0, l1, o, inv);
+                hr = box_hit_reference(h0, h1, o, inv);
+                if (hl) { if (hr) st.push(dr); cur = dl; }
+                else if (hr) cur = dr;
+                else cur = st.sp == 0 ? (uint32_t)TRAV_NONE : st.pop();
+            } else {
+                float tl, trr;
+                hl = box_hit_padded(l0, l1, o, inv, best.t, tl);
+                hr = box_hit_padded(h0, h1, o, inv, best.t, trr);
+                if (hl & hr) {
+                    bool left_first = !(trr < tl);
+                    st.push(left_first ? dr : dl);
+                    cur = left_first ? dl : dr;
+                } else if (hl) cur = dl;
+                else if (hr) cur = dr;
+                else cur = st.sp == 0 ? (uint32_t)TRAV_NONE : st.pop();
+            }
+        }
+        if ((cur & DESC_LEAF) && cur != TRAV_NONE) {
+            uint32_t first = cur & 0x07FFFFFFu, count = ((cur >> 27) & 15u) + 1u;
+            for (uint32_t i = 0; i < count; i++) test_prim<COUNT>(sc, first + i, o, d, a, t_min, best, cnt);
+            cur = st.sp == 0 ? (uint32_t)TRAV_NONE : st.pop();
+        }
+    }
+    tr.cur = cur; tr.sp = st.sp; tr.best = best;
+}
+
+// ------------------------------------------------------------------------------------------
 // hitRecord reconstruction for the winning primitive
 // ------------------------------------------------------------------------------------------
 struct HitRecord { f3 point, normal; uint32_t material; };

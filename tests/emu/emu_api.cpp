@@ -31,6 +31,22 @@ struct srt_ctx {
 
 namespace {
 
+// closest_hit() through the resumable traversal in the smallest possible quanta (one inner node per round), so
+// that the CPU suite checks that splitting a traversal changes nothing.
+template <bool EXACT>
+Hit query(const SceneView& sc, f3 o, f3 d, float t_min, uint32_t* stack, Counters& cnt)
+{
+    Trav tr;
+    tr.d = d;
+    trav_begin<EXACT, true, 1>(sc, o, t_min, tr, stack, cnt);
+    int budget = 1;
+    while (tr.cur != TRAV_NONE) {
+        trav_run<EXACT, true, 1>(sc, o, t_min, tr, stack, cnt, 1, budget);
+        budget = budget % 3 + 1;
+    }
+    return tr.best;
+}
+
 struct Totals { uint64_t v[7] = {0, 0, 0, 0, 0, 0, 0}; };
 
 // Items [i0, i1) of one pass, one lane at a time: the same per-lane functions the kernel calls, without the
@@ -55,7 +71,7 @@ void run_items(const SceneView& sc, const RenderArgs& ra, uint32_t i0, uint32_t 
             if (phase == LANE_RETURN) {
                 phase = lane_return(ln, ret, sc, ra, frames);
             } else if (phase == LANE_TRACE) {
-                Hit h = closest_hit<EXACT, true, 1>(sc, ln.qo, ln.qd, ln.qtmin, stack.data(), cnt);
+                Hit h = query<EXACT>(sc, ln.qo, ln.qd, ln.qtmin, stack.data(), cnt);
                 phase = lane_on_closest(ln, h, ret, sc, ra, frames, unit);
             } else {
                 uint32_t aux[4];
@@ -63,7 +79,7 @@ void run_items(const SceneView& sc, const RenderArgs& ra, uint32_t i0, uint32_t 
                 for (uint32_t li = 0; li < sc.n_lights; li++) {
                     f3 o, d;
                     lane_shadow_query(ln, sc, li, aux, unit, o, d);
-                    Hit h = closest_hit<EXACT, true, 1>(sc, o, d, 0.001f, stack.data(), cnt);
+                    Hit h = query<EXACT>(sc, o, d, 0.001f, stack.data(), cnt);
                     lane_on_shadow(ln, h, o, d, sc, li);
                 }
                 phase = lane_shade(ln, ln.former, ret, sc, ra, frames, aux, unit);

@@ -23,6 +23,9 @@
 
 namespace srt {
 
+#ifndef SRT_WAVES_PER_SIMD_MESH
+#define SRT_WAVES_PER_SIMD_MESH 4   // mesh_trace_kernel waits on node gathers: 983k triangles 38.6 ms at 3 waves/SIMD, 35.9 at 4 (33 spilled VGPRs)
+#endif
 #ifndef SRT_WAVES_PER_SIMD_BIG
 #define SRT_WAVES_PER_SIMD_BIG 3
 #endif
@@ -223,7 +226,7 @@ enum { MESH_IDLE = 0, MESH_CLOSEST = 1, MESH_SHADOW = 2, MESH_RETURN = 3 };
 constexpr int kWalkVote = 16, kWalkRounds = 1 << 24, kWalkSteps = 4;
 
 template <bool EXACT, bool COUNT>
-__global__ void __launch_bounds__(kBlock, SRT_WAVES_PER_SIMD_BIG) mesh_trace_kernel(SceneView sc, RenderArgs ra, f3* __restrict__ samples,
+__global__ void __launch_bounds__(kBlock, SRT_WAVES_PER_SIMD_MESH) mesh_trace_kernel(SceneView sc, RenderArgs ra, f3* __restrict__ samples,
                                                             unsigned long long* __restrict__ stats, uint32_t* __restrict__ work_counter,
                                                             int walk_vote, int rounds, int steps, uint32_t chunk)
 {
@@ -423,7 +426,8 @@ hipError_t launch_trace(const SceneView& sc, const RenderArgs& ra, bool exact, b
     static const int walk_vote = std::getenv("SRT_WALK_VOTE") ? std::atoi(std::getenv("SRT_WALK_VOTE")) : kWalkVote;
     static const int walk_rounds = std::getenv("SRT_WALK_ROUNDS") ? std::atoi(std::getenv("SRT_WALK_ROUNDS")) : kWalkRounds;
     static const int walk_steps = std::getenv("SRT_WALK_STEPS") ? std::atoi(std::getenv("SRT_WALK_STEPS")) : kWalkSteps;
-    if (allow_mesh && !stackless) {
+    static const bool force_mesh = std::getenv("SRT_FORCE_MESH_KERNEL") != nullptr;   // experiments only
+    if ((allow_mesh && !stackless) || force_mesh) {
 #define SRT_LAUNCH_MESH(E, C) hipLaunchKernelGGL((mesh_trace_kernel<E, C>), grid, block, 0, stream, sc, ra, s, d_stats, d_work_counter, walk_vote, walk_rounds, walk_steps, chunk)
         if (exact) { if (counted) SRT_LAUNCH_MESH(true, true); else SRT_LAUNCH_MESH(true, false); }
         else { if (counted) SRT_LAUNCH_MESH(false, true); else SRT_LAUNCH_MESH(false, false); }

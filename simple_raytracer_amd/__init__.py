@@ -3,7 +3,7 @@
 The compute path is libsrt.so (hand-written HIP kernels behind the C ABI of include/srt.h); this package
 is the host side: scene classes mirroring the reference's, the Game1 scene literals, and the render driver.
 """
-from . import _native
+from . import _native, model_loader
 from ._native import (LAYOUT_FRAME, LAYOUT_TILES, MODE_COLOR, MODE_DEPTH, MODE_DIFFUSE, MODE_LIGHTS, MODE_NORMAL, MODE_REFLECTION, WORLD_BVHNODE,
                       WORLD_SURFACELIST, SrtError)
 from .raytracing import (Camera, Light, LightList, Material, PointLight, RectAxis, Sphere, Surface, SurfaceList, Tri, TriMesh,

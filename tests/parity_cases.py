@@ -38,6 +38,9 @@ CASES = [
     ("mesh-2spp-depth8-bvhnode", lambda: helpers.mesh_spec(n=8), 96, 54, 2, 8, COLOR, BVH, 5),
     ("mesh-1spp-list", lambda: helpers.mesh_spec(n=10), 128, 72, 1, 4, COLOR, LIST, 1),
     ("mesh-rect-list", lambda: helpers.mesh_spec(n=8, with_rect=True), 96, 54, 2, 6, COLOR, LIST, 2),
+    ("mesh-lights-mode-list", lambda: helpers.mesh_spec(n=8), 96, 54, 2, 4, LIGHTS, LIST, 6),
+    ("mesh-reflection-mode-bvhnode", lambda: helpers.mesh_spec(n=8), 96, 54, 1, 8, REFLECTION, BVH, 2),
+    ("mesh-depth-mode-list", lambda: helpers.mesh_spec(n=10, with_rect=True), 96, 54, 1, 4, DEPTH, LIST, 1),
     ("mesh-only-tris", lambda: helpers.mesh_spec(n=8, with_spheres=False), 96, 54, 1, 4, COLOR, BVH, 2),
 ]
 

@@ -169,3 +169,17 @@ def test_gpu_full_size_window_parity_and_invariants(gpu, oracle):
     x0, y0, x1, y1 = win
     lsb, npx = helpers.max_lsb_diff(a[y0:y1, x0:x1], ref[y0:y1, x0:x1])
     assert lsb <= 1, (lsb, npx)
+
+
+def test_gpu_multi_pass_resolve(gpu_renderer_factory, oracle, monkeypatch):
+    """A sample buffer too small for the frame forces several trace passes with running sums in the resolve kernel;
+    the image must not change (small-scene kernel and mesh kernel)."""
+    monkeypatch.setenv("SRT_SAMPLE_BUFFER_MB", "1")     # 1 MiB: 160x90 pixels hold 6 samples per pass
+    r = gpu_renderer_factory()
+    try:
+        for case in (("multi-pass-default", helpers.default_spec, 160, 90, 16, 6, srt.MODE_COLOR, srt.WORLD_BVHNODE, 21),
+                     ("multi-pass-mesh", lambda: helpers.mesh_spec(n=8), 160, 90, 13, 4, srt.MODE_COLOR, srt.WORLD_SURFACELIST, 22)):
+            lsb, npx = parity_cases.assert_case(r, oracle, case)
+            assert lsb <= 1
+    finally:
+        r.close()

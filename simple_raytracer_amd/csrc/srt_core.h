@@ -292,20 +292,19 @@ SRT_HD bool test_tri(q4 p0, q4 p1, float acz, bool flip, f3 o, f3 d, float t_min
 template <bool COUNT>
 SRT_HD void test_prim(const SceneView& sc, uint32_t idx, f3 o, f3 d, float a, float t_min, Hit& best, Counters& cnt)
 {
-    q4 p0 = sc.prims[3 * idx], p2 = sc.prims[3 * idx + 2];
+    // all three words at once: one memory round trip per primitive, whatever its type turns out to be
+    q4 p0 = sc.prims[3 * idx], p1 = sc.prims[3 * idx + 1], p2 = sc.prims[3 * idx + 2];
     uint32_t info = fbits(p2.y), order = fbits(p2.z);
     uint32_t type = info & 3u;
     float t = 0.0f, u = 0.0f, v = 0.0f;
     bool h;
     if (type == PRIM_TRI) {
-        q4 p1 = sc.prims[3 * idx + 1];
         if (COUNT) cnt.tri_tests++;
         h = test_tri(p0, p1, p2.x, (info & INFO_FLIP) != 0u, o, d, t_min, best.t, t, u, v);
     } else if (type == PRIM_SPHERE) {
         if (COUNT) cnt.sphere_tests++;
         h = test_sphere(p0, o, d, a, t_min, best.t, t);
     } else {
-        q4 p1 = sc.prims[3 * idx + 1];
         if (COUNT) cnt.rect_tests++;
         h = test_rect(p0, p1.x, o, d, t_min, best.t, t);
     }

@@ -207,6 +207,7 @@ struct SceneView {
     uint32_t n_lights;
     uint32_t list_first, list_count;  // primitives scanned linearly (rects; everything in tiny scenes)
     uint32_t has_bvh;                 // nodes[0] is the root when set
+    uint32_t n_wide;                  // non-zero: `nodes` holds that many 64-byte wide nodes (4 words each) instead
     // Small reference trees only: the same nodes in depth-first (pre)order, 2 words each:
     // (min.xyz, desc) (max.xyz, index of the first node after this node's subtree).
     const q4* tiny;
@@ -334,25 +335,15 @@ SRT_HD bool box_hit_reference(q4 n0, q4 n1, f3 o, f3 inv)
     float tmax = min2(min2(max2(t1, t2), max2(t3, t4)), max2(t5, t6));
     return any_nan | !((tmax < 0.0f) | (tmin > tmax));
 }
-// Conservative slab test on padded boxes with culling against the closest hit so far.
-// fminf/fmaxf drop NaNs, which treats a NaN slab as "inside" -- the conservative reading.
-SRT_HD bool box_hit_padded(q4 n0, q4 n1, f3 o, f3 inv, float t_best, float& t_near)
-{
-    float t1 = (n0.x - o.x) * inv.x, t2 = (n1.x - o.x) * inv.x;
-    float t3 = (n0.y - o.y) * inv.y, t4 = (n1.y - o.y) * inv.y;
-    float t5 = (n0.z - o.z) * inv.z, t6 = (n1.z - o.z) * inv.z;
-    float tmin = max2(max2(min2(t1, t2), min2(t3, t4)), min2(t5, t6));
-    float tmax = min2(min2(max2(t1, t2), max2(t3, t4)), max2(t5, t6));
-    t_near = tmin;
-    return !((tmax < 0.0f) | (tmin > tmax) | (tmin > t_best));
-}
-
 // ------------------------------------------------------------------------------------------
 // Closest-hit query = Surface.hit(ray, t_min, +inf, record) on the committed world.
 //   EXACT:  BVHNode.hit order and semantics (left subtree, then right; no distance culling).
-//   !EXACT: SurfaceList.hit semantics through a padded SAH BVH, near child first.
-// The per-lane traversal stack lives in `stack_mem` with element stride STRIDE (an LDS column
-// on the GPU).
+//   !EXACT: SurfaceList.hit semantics through the library's own tree (a padded SAH tree collapsed to wide
+//           quantised nodes), nearest child first, culled against the closest hit so far.  fminf/fmaxf drop NaNs,
+//           which treats a NaN slab as "inside" -- the conservative reading.
+// closest_hit() answers worlds that need no traversal stack (flat lists, tiny reference trees); trees that do are
+// walked by trav_begin() / trav_run() below, with the per-lane stack in `stack_mem` at element stride STRIDE (an
+// LDS column on the GPU).
 // ------------------------------------------------------------------------------------------
 template <int STRIDE>
 struct LaneStack {
@@ -362,8 +353,8 @@ struct LaneStack {
     SRT_HD uint32_t pop() { sp--; return base[sp * STRIDE]; }
 };
 
-template <bool EXACT, bool COUNT, int STRIDE, bool STACKLESS = false>
-SRT_HD Hit closest_hit(const SceneView& sc, f3 o, f3 d, float t_min, uint32_t* stack_mem, Counters& cnt)
+template <bool EXACT, bool COUNT>
+SRT_HD Hit closest_hit(const SceneView& sc, f3 o, f3 d, float t_min, Counters& cnt)
 {
     Hit best;
     best.t = INFINITY; best.prim = NO_PRIM; best.u = 0.0f; best.v = 0.0f; best.order = 0u;
@@ -400,54 +391,6 @@ SRT_HD Hit closest_hit(const SceneView& sc, f3 o, f3 d, float t_min, uint32_t* s
         return best;
     }
 
-    if (!STACKLESS && sc.has_bvh) {   // STACKLESS: the caller knows that the scene is a flat list or a tiny tree
-        // Two loops inside one: descend through inner nodes until the lane holds a leaf (or nothing), then test the
-        // leaf's primitives.  The lanes of a wavefront wait for each other at the end of the descent, so that they
-        // run the (expensive) primitive tests together instead of every lane dragging the others through both kinds
-        // of step on every iteration.
-        const uint32_t kNone = 0xFFFFFFFFu;   // has the leaf bit: ends the descent like a leaf does
-        const f3 inv = mk3(1.0f / d.x, 1.0f / d.y, 1.0f / d.z);  // CustomRay.dirFrac (RaytracingClasses.cs:16-18)
-        LaneStack<STRIDE> st;
-        st.base = stack_mem; st.sp = 0;
-        q4 r0 = sc.nodes[0], r1 = sc.nodes[1];
-        if (COUNT) cnt.box_tests++;
-        float tn;
-        bool root_hit = EXACT ? box_hit_reference(r0, r1, o, inv) : box_hit_padded(r0, r1, o, inv, best.t, tn);
-        uint32_t cur = root_hit ? fbits(r0.w) : kNone;
-        while (cur != kNone) {
-            while (!(cur & DESC_LEAF)) {
-                // inner node: its two children are adjacent
-                q4 l0 = sc.nodes[2 * cur], l1 = sc.nodes[2 * cur + 1];
-                q4 h0 = sc.nodes[2 * cur + 2], h1 = sc.nodes[2 * cur + 3];
-                if (COUNT) cnt.box_tests += 2;
-                uint32_t dl = fbits(l0.w), dr = fbits(h0.w);
-                bool hl, hr;
-                if (EXACT) {
-                    hl = box_hit_reference(l0, l1, o, inv);
-                    hr = box_hit_reference(h0, h1, o, inv);
-                    if (hl) { if (hr) st.push(dr); cur = dl; }
-                    else if (hr) cur = dr;
-                    else cur = st.sp == 0 ? kNone : st.pop();
-                } else {
-                    float tl, tr;
-                    hl = box_hit_padded(l0, l1, o, inv, best.t, tl);
-                    hr = box_hit_padded(h0, h1, o, inv, best.t, tr);
-                    if (hl & hr) {
-                        bool left_first = !(tr < tl);
-                        st.push(left_first ? dr : dl);
-                        cur = left_first ? dl : dr;
-                    } else if (hl) cur = dl;
-                    else if (hr) cur = dr;
-                    else cur = st.sp == 0 ? kNone : st.pop();
-                }
-            }
-            if (cur != kNone) {
-                uint32_t first = cur & 0x07FFFFFFu, count = ((cur >> 27) & 15u) + 1u;
-                for (uint32_t i = 0; i < count; i++) test_prim<COUNT>(sc, first + i, o, d, a, t_min, best, cnt);
-                cur = st.sp == 0 ? kNone : st.pop();
-            }
-        }
-    }
     return best;
 }
 
@@ -462,12 +405,37 @@ SRT_HD Hit closest_hit(const SceneView& sc, f3 o, f3 d, float t_min, uint32_t* s
 enum : uint32_t { TRAV_NONE = 0xFFFFFFFFu, TRAV_NEW = 0xFFFFFFFEu };   // both carry the leaf bit; no real leaf has 16 primitives
 struct Trav { f3 d; Hit best; uint32_t cur; int32_t sp; };
 
+// One child of a wide node: slab test in the node's grid.  With plane = origin + step * q the form (plane - o) * inv
+// becomes q * (step * inv) + (origin - o) * inv = q * A + B, one fused multiply-add per plane.  The caller has
+// already picked, per axis, which of the child's two planes the ray meets first (by the sign of the direction), so
+// the entry distance is a max of three and the exit distance a min of three.  The rounding differs from the unfolded
+// form by a few ulp of the distances involved, orders of magnitude below the padding of the boxes (culling is
+// conservative, not part of the arithmetic contract); NaNs (0 * inf) drop out of fmaxf / fminf, i.e. never cull.
+// Returns the entry distance, +inf for a miss.
+SRT_HD float wide_child(uint32_t nx, uint32_t ny, uint32_t nz, uint32_t fx, uint32_t fy, uint32_t fz, int shift, f3 A, f3 B, float t_best)
+{
+    float n1 = __builtin_fmaf((float)((nx >> shift) & 255u), A.x, B.x), f1 = __builtin_fmaf((float)((fx >> shift) & 255u), A.x, B.x);
+    float n2 = __builtin_fmaf((float)((ny >> shift) & 255u), A.y, B.y), f2 = __builtin_fmaf((float)((fy >> shift) & 255u), A.y, B.y);
+    float n3 = __builtin_fmaf((float)((nz >> shift) & 255u), A.z, B.z), f3_ = __builtin_fmaf((float)((fz >> shift) & 255u), A.z, B.z);
+    float tmin = max2(max2(n1, n2), n3);
+    float tmax = min2(min2(f1, f2), f3_);
+    bool hit = !((tmax < 0.0f) | (tmin > tmax) | (tmin > t_best));
+    return hit ? max2(tmin, -3.0e38f) : INFINITY;
+}
+SRT_HD void sort_pair(float& ta, uint32_t& ca, float& tb, uint32_t& cb)
+{
+    bool swap = tb < ta;
+    float t = swap ? ta : tb; uint32_t c = swap ? ca : cb;
+    ta = swap ? tb : ta; ca = swap ? cb : ca;
+    tb = t; cb = c;
+}
+
 template <bool EXACT, bool COUNT, int STRIDE>
 SRT_HD void trav_begin(const SceneView& sc, f3 o, float t_min, Trav& tr, uint32_t* stack_mem, Counters& cnt)
 {
     tr.sp = 0;
     if (sc.has_bvh == 0u || (EXACT && sc.n_tiny != 0u)) {
-        tr.best = closest_hit<EXACT, COUNT, STRIDE, true>(sc, o, tr.d, t_min, stack_mem, cnt);
+        tr.best = closest_hit<EXACT, COUNT>(sc, o, tr.d, t_min, cnt);
         tr.cur = TRAV_NONE;
         return;
     }
@@ -476,13 +444,15 @@ SRT_HD void trav_begin(const SceneView& sc, f3 o, float t_min, Trav& tr, uint32_
     const f3 d = tr.d;
     const float a = lensq3(d);
     for (uint32_t i = 0; i < sc.list_count; i++) test_prim<COUNT>(sc, sc.list_first + i, o, d, a, t_min, best, cnt);
-    const f3 inv = mk3(1.0f / d.x, 1.0f / d.y, 1.0f / d.z);
-    q4 r0 = sc.nodes[0], r1 = sc.nodes[1];
-    if (COUNT) cnt.box_tests++;
-    float tn;
-    bool root_hit = EXACT ? box_hit_reference(r0, r1, o, inv) : box_hit_padded(r0, r1, o, inv, best.t, tn);
-    tr.cur = root_hit ? fbits(r0.w) : (uint32_t)TRAV_NONE;
     tr.best = best;
+    if (EXACT) {
+        const f3 inv = mk3(1.0f / d.x, 1.0f / d.y, 1.0f / d.z);
+        q4 r0 = sc.nodes[0], r1 = sc.nodes[1];
+        if (COUNT) cnt.box_tests++;
+        tr.cur = box_hit_reference(r0, r1, o, inv) ? fbits(r0.w) : (uint32_t)TRAV_NONE;
+    } else {
+        tr.cur = 0u;   // the wide root; its children's boxes are tested when it is visited
+    }
 }
 
 template <bool EXACT, bool COUNT, int STRIDE>
@@ -497,28 +467,41 @@ SRT_HD void trav_run(const SceneView& sc, f3 o, float t_min, Trav& tr, uint32_t*
     uint32_t cur = tr.cur;
     for (int r = 0; r < rounds && cur != TRAV_NONE; r++) {
         for (int s = 0; s < steps && !(cur & DESC_LEAF); s++) {
-            q4 l0 = sc.nodes[2 * cur], l1 = sc.nodes[2 * cur + 1];
-            q4 h0 = sc.nodes[2 * cur + 2], h1 = sc.nodes[2 * cur + 3];
-            if (COUNT) cnt.box_tests += 2;
-            uint32_t dl = fbits(l0.w), dr = fbits(h0.w);
-            bool hl, hr;
             if (EXACT) {
-                hl = box_hit_reference(l0, l1, o, inv);
-                hr = box_hit_reference(h0, h1, o, inv);
+                // the reference tree: two adjacent children, left subtree first, no distance culling
+                q4 l0 = sc.nodes[2 * cur], l1 = sc.nodes[2 * cur + 1];
+                q4 h0 = sc.nodes[2 * cur + 2], h1 = sc.nodes[2 * cur + 3];
+                if (COUNT) cnt.box_tests += 2;
+                uint32_t dl = fbits(l0.w), dr = fbits(h0.w);
+                bool hl = box_hit_reference(l0, l1, o, inv);
+                bool hr = box_hit_reference(h0, h1, o, inv);
                 if (hl) { if (hr) st.push(dr); cur = dl; }
                 else if (hr) cur = dr;
                 else cur = st.sp == 0 ? (uint32_t)TRAV_NONE : st.pop();
             } else {
-                float tl, trr;
-                hl = box_hit_padded(l0, l1, o, inv, best.t, tl);
-                hr = box_hit_padded(h0, h1, o, inv, best.t, trr);
-                if (hl & hr) {
-                    bool left_first = !(trr < tl);
-                    st.push(left_first ? dr : dl);
-                    cur = left_first ? dl : dr;
-                } else if (hl) cur = dl;
-                else if (hr) cur = dr;
-                else cur = st.sp == 0 ? (uint32_t)TRAV_NONE : st.pop();
+                // a wide node: up to four quantised child boxes, nearest first, the others pushed far to near
+                q4 w0 = sc.nodes[4 * cur], w1 = sc.nodes[4 * cur + 1], w2 = sc.nodes[4 * cur + 2], w3 = sc.nodes[4 * cur + 3];
+                uint32_t meta = fbits(w0.w);
+                uint32_t nk = meta >> 24;
+                if (COUNT) cnt.box_tests += nk;
+                f3 A = mk3(bitsf((meta & 255u) << 23) * inv.x, bitsf(((meta >> 8) & 255u) << 23) * inv.y, bitsf(((meta >> 16) & 255u) << 23) * inv.z);
+                f3 B = mk3((w0.x - o.x) * inv.x, (w0.y - o.y) * inv.y, (w0.z - o.z) * inv.z);
+                // per axis: the planes the ray enters through / leaves through (a negative direction enters at hi)
+                const bool bx = (fbits(d.x) >> 31) != 0u, by = (fbits(d.y) >> 31) != 0u, bz = (fbits(d.z) >> 31) != 0u;
+                uint32_t lx = fbits(w1.x), ly = fbits(w1.y), lz = fbits(w1.z), hx = fbits(w1.w), hy = fbits(w2.x), hz = fbits(w2.y);
+                uint32_t nx = bx ? hx : lx, fx = bx ? lx : hx, ny = by ? hy : ly, fy = by ? ly : hy, nz = bz ? hz : lz, fz = bz ? lz : hz;
+                uint32_t c0 = fbits(w2.z), c1 = fbits(w2.w), c2 = fbits(w3.x), c3 = fbits(w3.y);
+                float t0 = wide_child(nx, ny, nz, fx, fy, fz, 0, A, B, best.t);
+                float t1 = nk > 1u ? wide_child(nx, ny, nz, fx, fy, fz, 8, A, B, best.t) : INFINITY;
+                float t2 = nk > 2u ? wide_child(nx, ny, nz, fx, fy, fz, 16, A, B, best.t) : INFINITY;
+                float t3 = nk > 3u ? wide_child(nx, ny, nz, fx, fy, fz, 24, A, B, best.t) : INFINITY;
+                sort_pair(t0, c0, t1, c1); sort_pair(t2, c2, t3, c3);
+                sort_pair(t0, c0, t2, c2); sort_pair(t1, c1, t3, c3);
+                sort_pair(t1, c1, t2, c2);
+                if (t3 < INFINITY) st.push(c3);
+                if (t2 < INFINITY) st.push(c2);
+                if (t1 < INFINITY) st.push(c1);
+                cur = t0 < INFINITY ? c0 : (st.sp == 0 ? (uint32_t)TRAV_NONE : st.pop());
             }
         }
         if ((cur & DESC_LEAF) && cur != TRAV_NONE) {

@@ -81,12 +81,10 @@ __global__ void __launch_bounds__(kBlock, SMALL ? SRT_WAVES_PER_SIMD : SRT_WAVES
                                                        unsigned long long* __restrict__ stats, uint32_t* __restrict__ work_counter,
                                                        int trace_vote, uint32_t chunk)
 {
-    __shared__ uint32_t lds_stack[SMALL ? 1 : kWaves * STACK_DEPTH * 64];
     __shared__ float lds_frames[SMALL ? kWaves * kLdsFrameLevels * 14 * 64 : 1];
     __shared__ float unit[UNIT_TABLE];   // (d - 100) / 100 for the RNG's base-200 digits
     __shared__ q4 small_tables[SMALL ? kSmallWords : 1];
     const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
-    uint32_t* my_stack = SMALL ? lds_stack : &lds_stack[wave * (STACK_DEPTH * 64) + lane];
     if (threadIdx.x < (uint32_t)UNIT_TABLE) unit[threadIdx.x] = (float)((int)threadIdx.x - 100) / 100.0f;
     SceneView sc = gsc;
     if (SMALL) {
@@ -157,7 +155,7 @@ __global__ void __launch_bounds__(kBlock, SMALL ? SRT_WAVES_PER_SIMD : SRT_WAVES
             // ---- TRACE: closest-hit query of a tree node
             if (COUNT) { sect[0]++; sect[1] += (uint32_t)__popcll(__ballot(phase == LANE_TRACE)); }
             if (phase == LANE_TRACE) {
-                Hit h = closest_hit<EXACT, COUNT, 64, SMALL>(sc, ln.qo, ln.qd, ln.qtmin, my_stack, cnt);
+                Hit h = closest_hit<EXACT, COUNT>(sc, ln.qo, ln.qd, ln.qtmin, cnt);
                 SRT_MARK(PROF_CLOSEST);
                 f3 ret;
                 phase = lane_on_closest(ln, h, ret, sc, ra, frames, unit);
@@ -175,7 +173,7 @@ __global__ void __launch_bounds__(kBlock, SMALL ? SRT_WAVES_PER_SIMD : SRT_WAVES
                     f3 o, d;
                     lane_shadow_query(ln, sc, li, aux, unit, o, d);
                     SRT_MARK(PROF_SHADOW_SETUP);
-                    Hit h = closest_hit<EXACT, COUNT, 64, SMALL>(sc, o, d, 0.001f, my_stack, cnt);
+                    Hit h = closest_hit<EXACT, COUNT>(sc, o, d, 0.001f, cnt);
                     SRT_MARK(PROF_SHADOW_QUERY);
                     lane_on_shadow(ln, h, o, d, sc, li);
                     SRT_MARK(PROF_LIGHT_EVAL);
@@ -223,7 +221,7 @@ __global__ void __launch_bounds__(kBlock, SMALL ? SRT_WAVES_PER_SIMD : SRT_WAVES
 // kWalkVote 16 instead of 32: 39.8.  So the defaults never split a traversal; what pays is one copy of the
 // traversal code for both kinds of query, short descents between leaf tests, and starting traversals in batches.
 enum { MESH_IDLE = 0, MESH_CLOSEST = 1, MESH_SHADOW = 2, MESH_RETURN = 3 };
-constexpr int kWalkVote = 16, kWalkRounds = 1 << 24, kWalkSteps = 4;
+constexpr int kWalkVote = 16, kWalkRounds = 1 << 24, kWalkSteps = 2;
 
 template <bool EXACT, bool COUNT>
 __global__ void __launch_bounds__(kBlock, SRT_WAVES_PER_SIMD_MESH) mesh_trace_kernel(SceneView sc, RenderArgs ra, f3* __restrict__ samples,
@@ -422,12 +420,10 @@ hipError_t launch_trace(const SceneView& sc, const RenderArgs& ra, bool exact, b
     const bool stackless = sc.has_bvh == 0u || (exact && sc.n_tiny != 0u);
     const bool small = allow_small && stackless && sc.n_prims <= kSmallPrims && sc.n_materials <= kSmallMaterials;
     // Scenes whose tree is walked with a stack get the kernel that schedules traversal in quanta.
-    static const bool allow_mesh = !std::getenv("SRT_NO_MESH_KERNEL");
     static const int walk_vote = std::getenv("SRT_WALK_VOTE") ? std::atoi(std::getenv("SRT_WALK_VOTE")) : kWalkVote;
     static const int walk_rounds = std::getenv("SRT_WALK_ROUNDS") ? std::atoi(std::getenv("SRT_WALK_ROUNDS")) : kWalkRounds;
     static const int walk_steps = std::getenv("SRT_WALK_STEPS") ? std::atoi(std::getenv("SRT_WALK_STEPS")) : kWalkSteps;
-    static const bool force_mesh = std::getenv("SRT_FORCE_MESH_KERNEL") != nullptr;   // experiments only
-    if ((allow_mesh && !stackless) || force_mesh) {
+    if (!stackless) {
 #define SRT_LAUNCH_MESH(E, C) hipLaunchKernelGGL((mesh_trace_kernel<E, C>), grid, block, 0, stream, sc, ra, s, d_stats, d_work_counter, walk_vote, walk_rounds, walk_steps, chunk)
         if (exact) { if (counted) SRT_LAUNCH_MESH(true, true); else SRT_LAUNCH_MESH(true, false); }
         else { if (counted) SRT_LAUNCH_MESH(false, true); else SRT_LAUNCH_MESH(false, false); }

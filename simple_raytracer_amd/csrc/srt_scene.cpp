@@ -330,6 +330,134 @@ struct SahBuilder {
     }
 };
 
+
+// ---------------------------------------------------------------------------------------
+// Wide nodes: the SAH tree collapsed to up to four children per node, child boxes quantised to
+// 8 bits per coordinate inside the box of the node, 64 bytes per node.  One visit then costs a
+// lane four 16-byte loads for four boxes (the binary tree: four loads for two boxes), and a
+// query visits about half as many nodes -- the texture-address unit, which handles one lane's
+// load at a time, is what limits the traversal of a large mesh.
+//   word 0: origin.xyz (the lower corner of the children's union), ex | ey << 8 | ez << 16 | children << 24
+//           (e = biased float exponent of the grid step along the axis: step = 2^(e - 127))
+//   word 1: lo.x of the 4 children (one byte each), lo.y, lo.z, hi.x
+//   word 2: hi.y, hi.z, child 0, child 1
+//   word 3: child 2, child 3, -, -
+// Child descriptors: index of a wide node, or DESC_LEAF | (count - 1) << 27 | first primitive.
+// A decoded box (origin + step * byte, evaluated in float exactly as the kernel does) always
+// contains the padded box it stands for.
+// The traversal pushes the children it does not enter, at most (children - 1) per node.  `budget` is the number
+// of stack entries still free on the way down; a node only takes as many children as leave every child at least
+// the height of its binary subtree (a binary subtree of height h can always be emitted with one push per level),
+// so no traversal ever needs more than STACK_DEPTH entries.
+// ---------------------------------------------------------------------------------------
+struct WideBuilder {
+    const std::vector<NodeRec>& n2;
+    std::vector<uint32_t> height;     // of the binary subtree under each binary node (a leaf: 0)
+    std::vector<q4> out;
+    uint32_t max_depth = 0;
+
+    explicit WideBuilder(const std::vector<NodeRec>& binary) : n2(binary) {}
+
+    static float step_of(uint32_t e) { return bitsf(e << 23); }
+    static float decode(float origin, uint32_t e, uint32_t q) { return origin + step_of(e) * (float)q; }
+
+    uint32_t measure(uint32_t idx)
+    {
+        uint32_t h = 0;
+        if (!(n2[idx].desc & DESC_LEAF)) {
+            uint32_t a = measure(n2[idx].desc), b = measure(n2[idx].desc + 1);
+            h = 1 + (a > b ? a : b);
+        }
+        height[idx] = h;
+        return h;
+    }
+
+    void emit(uint32_t idx, uint32_t slot, uint32_t budget, uint32_t depth)
+    {
+        if (depth > max_depth) max_depth = depth;
+        uint32_t kids[4];
+        uint32_t nk = 0;
+        if (n2[idx].desc & DESC_LEAF) {
+            kids[nk++] = idx;
+        } else {
+            kids[0] = n2[idx].desc; kids[1] = n2[idx].desc + 1; nk = 2;
+            while (nk < 4) {
+                // expand the inner child with the largest box, if the stack budget of every child still holds its height
+                int pick = -1;
+                float area = -1.0f;
+                for (uint32_t i = 0; i < nk; i++) {
+                    if (n2[kids[i]].desc & DESC_LEAF) continue;
+                    float a = SahBuilder::half_area(n2[kids[i]].box);
+                    if (a > area) { area = a; pick = (int)i; }
+                }
+                if (pick < 0) break;
+                uint32_t c = n2[kids[pick]].desc;
+                uint32_t tallest = 0;
+                for (uint32_t i = 0; i < nk; i++) {
+                    uint32_t h = (int)i == pick ? (height[c] > height[c + 1] ? height[c] : height[c + 1]) : height[kids[i]];
+                    if (h > tallest) tallest = h;
+                }
+                if (nk + tallest > budget) break;        // (nk + 1 - 1) pushes here + the tallest child's worst case
+                for (uint32_t i = nk; i > (uint32_t)pick + 1; i--) kids[i] = kids[i - 1];
+                kids[pick] = c; kids[pick + 1] = c + 1;
+                nk++;
+            }
+        }
+        // the grid: origin = lower corner of the children's union, step = the power of two that spans it in 255 steps
+        Box u = SahBuilder::empty_box();
+        for (uint32_t i = 0; i < nk; i++) SahBuilder::grow(u, n2[kids[i]].box);
+        uint32_t e[3], qlo[3][4], qhi[3][4];
+        for (int k = 0; k < 3; k++) {
+            float ext = u.mx[k] - u.mn[k];
+            int ex = 0;
+            std::frexp(ext / 255.0f, &ex);               // ext / 255 = m * 2^ex with m in [0.5, 1)  =>  2^ex >= ext / 255
+            int be = ex + 127;
+            if (!(ext > 0.0f) || be < 1) be = 1;
+            for (;; be++) {
+                bool fits = true;
+                for (uint32_t i = 0; i < nk && fits; i++) {
+                    const Box& b = n2[kids[i]].box;
+                    float st = step_of((uint32_t)be);
+                    long lo = (long)std::floor((b.mn[k] - u.mn[k]) / st), hi = (long)std::ceil((b.mx[k] - u.mn[k]) / st);
+                    if (lo < 0) lo = 0;
+                    if (hi < 0) hi = 0;
+                    if (lo > 255) lo = 255;
+                    while (lo > 0 && decode(u.mn[k], (uint32_t)be, (uint32_t)lo) > b.mn[k]) lo--;
+                    while (hi <= 255 && decode(u.mn[k], (uint32_t)be, (uint32_t)hi) < b.mx[k]) hi++;
+                    if (hi > 255 || decode(u.mn[k], (uint32_t)be, (uint32_t)lo) > b.mn[k]) { fits = false; break; }
+                    qlo[k][i] = (uint32_t)lo; qhi[k][i] = (uint32_t)hi;
+                }
+                if (fits || be >= 254) break;            // a coarser grid always fits eventually
+            }
+            e[k] = (uint32_t)be;
+            for (uint32_t i = nk; i < 4; i++) { qlo[k][i] = 0; qhi[k][i] = 0; }
+        }
+        auto pack = [](const uint32_t q[4]) { return q[0] | (q[1] << 8) | (q[2] << 16) | (q[3] << 24); };
+        uint32_t child[4] = {0u, 0u, 0u, 0u};
+        for (uint32_t i = 0; i < nk; i++) {
+            const NodeRec& c = n2[kids[i]];
+            if (c.desc & DESC_LEAF) { child[i] = c.desc; continue; }
+            uint32_t at = (uint32_t)(out.size() / 4);
+            out.resize(out.size() + 4);
+            child[i] = at;
+            emit(kids[i], at, budget - (nk - 1u), depth + 1);
+        }
+        q4* w = &out[(size_t)slot * 4];
+        w[0] = mkq(u.mn[0], u.mn[1], u.mn[2], bitsf(e[0] | (e[1] << 8) | (e[2] << 16) | (nk << 24)));
+        w[1] = mkq(bitsf(pack(qlo[0])), bitsf(pack(qlo[1])), bitsf(pack(qlo[2])), bitsf(pack(qhi[0])));
+        w[2] = mkq(bitsf(pack(qhi[1])), bitsf(pack(qhi[2])), bitsf(child[0]), bitsf(child[1]));
+        w[3] = mkq(bitsf(child[2]), bitsf(child[3]), 0.0f, 0.0f);
+    }
+    void run()
+    {
+        height.assign(n2.size(), 0u);
+        measure(0);
+        out.clear();
+        out.resize(4);
+        emit(0, 0, (uint32_t)STACK_DEPTH, 1);
+    }
+};
+
 // primitive record for global surface index `g`
 void emit_prim(const HostScene& in, uint32_t g, uint32_t order, std::vector<q4>& prims)
 {
@@ -551,9 +679,12 @@ int flatten_scene(const HostScene& in, int world_kind, FlatScene& out, std::stri
             SahBuilder b(pb);
             b.run();
             for (uint32_t i = 0; i < b.leaf_order.size(); i++) emit_prim(in, b.leaf_order[i], b.leaf_order[i], out.prims);
-            emit_nodes(b.nodes, out.nodes);
-            out.n_nodes = (uint32_t)b.nodes.size();
-            out.bvh_depth = b.max_depth;
+            WideBuilder w(b.nodes);
+            w.run();
+            out.nodes.swap(w.out);
+            out.n_wide = (uint32_t)(out.nodes.size() / 4);
+            out.n_nodes = out.n_wide;
+            out.bvh_depth = w.max_depth;
         }
         if (out.bvh_depth > (uint32_t)STACK_DEPTH) { err = "BVH deeper than the traversal stack"; return SRT_E_LIMIT; }
         out.has_bvh = 1;

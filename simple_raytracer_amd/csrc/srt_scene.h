@@ -32,7 +32,7 @@ struct HostScene {
 // Device-ready arrays in the layout srt_core.h documents.
 struct FlatScene {
     std::vector<q4> nodes, prims, normals, materials, lights, tiny;
-    uint32_t n_lights = 0, list_first = 0, list_count = 0, has_bvh = 0, n_tiny = 0;
+    uint32_t n_lights = 0, list_first = 0, list_count = 0, has_bvh = 0, n_tiny = 0, n_wide = 0;
     uint32_t n_nodes = 0, bvh_depth = 0, n_prims = 0, n_materials = 0;
 
     // The view the kernels take, over device (or, for the CPU harness, host) copies of the arrays.
@@ -41,7 +41,7 @@ struct FlatScene {
         SceneView v;
         v.nodes = d_nodes; v.prims = d_prims; v.normals = d_normals; v.materials = d_materials; v.lights = d_lights; v.tiny = d_tiny;
         v.n_lights = n_lights; v.list_first = list_first; v.list_count = list_count; v.has_bvh = has_bvh; v.n_tiny = n_tiny;
-        v.n_nodes = n_nodes; v.n_prims = n_prims; v.n_materials = n_materials;
+        v.n_nodes = n_nodes; v.n_prims = n_prims; v.n_materials = n_materials; v.n_wide = n_wide;
         v.hit_prims = d_prims;
         return v;
     }

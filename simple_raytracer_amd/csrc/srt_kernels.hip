@@ -218,7 +218,8 @@ __global__ void __launch_bounds__(kBlock, SMALL ? SRT_WAVES_PER_SIMD : SRT_WAVES
 // then test the leaf if one was reached".  Measured on a 983,040-triangle mesh (1080p, 64 spp; ms per frame): the
 // closest-hit / light sections of trace_kernel 56.1; quanta of 2 x 8 steps 58.2, 8 x 8 48.6, 32 x 8 44.7; unbounded
 // quanta (every traversal runs to its end once started) with 8 steps 43.3, 4 steps 40.8, 2 steps 43.1; and with
-// kWalkVote 16 instead of 32: 39.8.  So the defaults never split a traversal; what pays is one copy of the
+// kWalkVote 16 instead of 32: 39.8 (all of these on the binary SAH tree; on the 4-wide tree that replaced it 2 steps
+// are best: 34.2 / 32.6 / 34.8 / 39.5 ms for 1 / 2 / 3 / 6).  So the defaults never split a traversal; what pays is one copy of the
 // traversal code for both kinds of query, short descents between leaf tests, and starting traversals in batches.
 enum { MESH_IDLE = 0, MESH_CLOSEST = 1, MESH_SHADOW = 2, MESH_RETURN = 3 };
 constexpr int kWalkVote = 16, kWalkRounds = 1 << 24, kWalkSteps = 2;

@@ -183,3 +183,22 @@ def test_gpu_multi_pass_resolve(gpu_renderer_factory, oracle, monkeypatch):
             assert lsb <= 1
     finally:
         r.close()
+
+
+def test_gpu_c_host_example_matches_python_host(gpu, tmp_path):
+    """examples/game1_host.c builds the Game1 scene and camera in C and renders through the C ABI alone (asynchronous
+    entry points); its frame must be the one the Python host mirror gets for the same parameters."""
+    import subprocess
+    exe = os.path.join(helpers.ROOT, "examples", "game1_host")
+    assert os.path.exists(exe), "build it with `make -C examples` (done by __graft_entry__.build())"
+    out = tmp_path / "frame.ppm"
+    w, h, spp, depth, seed = 160, 90, 3, 4, 7
+    subprocess.run([exe, str(w), str(h), str(spp), str(depth), str(seed), str(out)], check=True, timeout=100)
+    raw = out.read_bytes()
+    header = ("P6\n%d %d\n255\n" % (w, h)).encode()
+    assert raw.startswith(header)
+    rgb = np.frombuffer(raw[len(header):], dtype=np.uint8).reshape(h, w, 3)[::-1]      # the file is written top-down
+    world, lights, cam = helpers.default_spec().host(w, h)
+    gpu.set_scene(world, lights, cam, world_kind=srt.WORLD_BVHNODE)
+    img = gpu.render(w, h, samples=spp, max_depth=depth, seed=seed)
+    assert np.array_equal(rgb, srt.rgba_to_rgb8(img))

@@ -1,18 +1,21 @@
-// srt_kernels.hip -- gfx950 kernels: the persistent trace kernel, the sample resolve kernel and
-// the tile assembly kernel.
+// srt_kernels.hip -- gfx950 kernels: the two persistent trace kernels, the sample resolve kernel and the tile
+// assembly kernel.
 //
-// trace_kernel.  Work items are (pixel, sample) pairs.  Wavefronts are persistent: each one
-// draws chunks of items from a global counter (one atomic per chunk) and deals them to its
-// idle lanes with a ballot + prefix count, so lanes whose ray tree ended are refilled at once
-// instead of idling until the slowest lane of the wavefront is done.  A lane is a small state
-// machine (srt_path.h): it is either waiting for the closest-hit query of a tree node (TRACE)
-// or owes the shadow queries and the shading of a node that was hit (LIGHT).  Each trip of the
-// main loop the wavefront votes for one of the two code sections and every lane in that phase
-// executes it together; lanes in the other phase wait.  That keeps the 64 lanes on the same
-// instructions instead of serialising the sections under divergent masks.
-// The BVH traversal stack is a per-wavefront slab of LDS with one column per lane (entry i of
-// lane l at [i][l]: conflict-free); the ray-tree frames (one per pending recursion level) are
-// private memory.
+// Work items are (pixel, sample) pairs.  Wavefronts are persistent: each one draws chunks of items from a global
+// counter (one atomic per chunk) and deals them to its idle lanes with a ballot + prefix count, so lanes whose ray
+// tree ended are refilled at once instead of idling until the slowest lane of the wavefront is done.  A lane is a
+// small state machine over the sample's ray tree (srt_path.h).  Each trip of the main loop the wavefront votes for
+// one code section and every lane that is in the matching phase executes it together; the other lanes wait.  That
+// keeps the 64 lanes on the same instructions instead of serialising the sections under divergent masks.
+//
+//   trace_kernel        worlds that need no traversal stack (flat lists, reference trees of a few nodes): phases
+//                       TRACE / LIGHT / RETURN, a query is a code section that every participating lane sits through.
+//   mesh_trace_kernel   worlds with a tree that is walked with a stack: a traversal is a resumable object and
+//                       shadow queries are lane states of their own (one copy of the traversal code).
+//
+// The traversal stack is a per-wavefront slab of LDS with one column per lane (entry i of lane l at [i][l]:
+// conflict-free); the ray-tree frames (one per pending recursion level) are LDS for the first levels of small
+// scenes and private memory otherwise.
 #include <hip/hip_runtime.h>
 
 #include <cstdlib>

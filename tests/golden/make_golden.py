@@ -27,6 +27,9 @@ GOLDEN = {
     "default_rect_list_2spp_64x36": ("default_spec", {"with_rect": True}, 64, 36, 2, 4, orc.MODE_COLOR, orc.WORLD_SURFACELIST, 1),
     "mesh_color_1spp_bvhnode_64x36": ("mesh_spec", {"n": 10}, 64, 36, 1, 4, orc.MODE_COLOR, orc.WORLD_BVHNODE, 1),
     "mesh_color_4spp_list_64x36": ("mesh_spec", {"n": 10, "with_rect": True}, 64, 36, 4, 6, orc.MODE_COLOR, orc.WORLD_SURFACELIST, 1),
+    "teapot_dae_normal_list_64x36": ("teapot_spec", {}, 64, 36, 1, 4, orc.MODE_NORMAL, orc.WORLD_SURFACELIST, 1),
+    "teapot_dae_color_1spp_list_64x36": ("teapot_spec", {}, 64, 36, 1, 4, orc.MODE_COLOR, orc.WORLD_SURFACELIST, 1),
+    "teapot_dae_color_4spp_bvhnode_64x36": ("teapot_spec", {}, 64, 36, 4, 4, orc.MODE_COLOR, orc.WORLD_BVHNODE, 1),
 }
 
 
@@ -39,7 +42,10 @@ def render(entry):
 
 
 if __name__ == "__main__":
+    only = sys.argv[1:]          # optional: names to (re)generate
     for name, entry in GOLDEN.items():
+        if only and name not in only:
+            continue
         img, nodes, counts = render(entry)
         np.savez_compressed(os.path.join(HERE, name + ".npz"), image=img, nodes_per_pixel=nodes, counts=counts)
         print(name, img.shape, counts.tolist())

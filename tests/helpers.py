@@ -168,6 +168,18 @@ def mesh_spec(kind="sphere", n=16, with_spheres=True, with_rect=False):
     return s
 
 
+def teapot_spec():
+    """The reference's teapot.dae (6,320 triangles, from the committed fixture) with mat6 (Game1.cs:109), the loader's
+    fallback camera Camera((0,0,6), (0,0,0), 29) (ModelLoader.cs:105) and the two Game1 lights (Game1.cs:140-141)."""
+    d = np.load(os.path.join(GOLDEN, "teapot_dae.npz"))
+    s = SceneSpec()
+    s.materials = [((1.0, 0.5, 0.5), 0.0, 0.85, (0, 0, 0))]
+    s.meshes.append((d["pos9"], d["nrm9"], 0, False, True))
+    s.lights = [((6.0, 2.0, 3.0), 5.0, None), ((0.0, 0.0, -12.0), 2.5, None)]
+    s.camera = ((0, 0, 6), (0, 0, 0), 29)
+    return s
+
+
 def max_lsb_diff(a, b):
     """Largest per-channel difference between two packed RGBA images, and the number of differing pixels."""
     da = orc.rgba_to_rgb8(np.asarray(a)).astype(np.int32)

@@ -202,3 +202,12 @@ def test_gpu_c_host_example_matches_python_host(gpu, tmp_path):
     gpu.set_scene(world, lights, cam, world_kind=srt.WORLD_BVHNODE)
     img = gpu.render(w, h, samples=spp, max_depth=depth, seed=seed)
     assert np.array_equal(rgb, srt.rgba_to_rgb8(img))
+
+
+import random_scenes  # noqa: E402
+
+
+@pytest.mark.parametrize("seed", range(40))
+def test_gpu_random_scene_matches_oracle(gpu, oracle, seed):
+    lsb, npx, same_counts, what = random_scenes.run(gpu, oracle, seed)
+    assert lsb <= 1 and same_counts, (lsb, npx, what)

@@ -54,3 +54,12 @@ def test_sah_tree_matches_linear_scan(emu, oracle, case):
     for k in ("rays_path", "rays_shadow", "hit_nodes"):
         assert st[k] == ost[k], (case[0], k)
     assert st["bvh_nodes"] > 100 and st["box_tests"] > 0
+
+
+import random_scenes  # noqa: E402
+
+
+@pytest.mark.parametrize("seed", range(24))
+def test_random_scene_matches_oracle(emu, oracle, seed):
+    lsb, npx, same_counts, what = random_scenes.run(emu, oracle, seed)
+    assert (lsb, npx) == (0, 0) and same_counts, what

@@ -95,11 +95,12 @@ int main(int argc, char** argv)
     fprintf(stderr, "%dx%d, %d spp, depth %d: %.3f ms on the device, %llu rays, %.1f Mrays/s, %lu polls\n", width, height, samples,
             max_depth, st.kernel_ms, (unsigned long long)st.rays_path, (double)st.rays_path / st.kernel_ms / 1e3, polls);
 
-    /* image row 0 is the bottom of the camera's view (Game1 draws the texture flipped): write rows top-down */
+    /* rows in buffer order, as the reference saves its Color[] (buffer row 0 is the bottom of the camera's view and
+       the top of the saved picture: the scene is set up for that, see testrender.jpg) */
     FILE* f = fopen(path, "wb");
     if (!f) { perror(path); return 1; }
     fprintf(f, "P6\n%d %d\n255\n", width, height);
-    for (int y = height - 1; y >= 0; y--)
+    for (int y = 0; y < height; y++)
         for (int x = 0; x < width; x++) {
             uint32_t c = frame[(size_t)x + (size_t)y * (size_t)width];
             unsigned char rgb[3] = {(unsigned char)(c & 255u), (unsigned char)((c >> 8) & 255u), (unsigned char)((c >> 16) & 255u)};

@@ -197,7 +197,7 @@ def test_gpu_c_host_example_matches_python_host(gpu, tmp_path):
     raw = out.read_bytes()
     header = ("P6\n%d %d\n255\n" % (w, h)).encode()
     assert raw.startswith(header)
-    rgb = np.frombuffer(raw[len(header):], dtype=np.uint8).reshape(h, w, 3)[::-1]      # the file is written top-down
+    rgb = np.frombuffer(raw[len(header):], dtype=np.uint8).reshape(h, w, 3)            # rows in buffer order
     world, lights, cam = helpers.default_spec().host(w, h)
     gpu.set_scene(world, lights, cam, world_kind=srt.WORLD_BVHNODE)
     img = gpu.render(w, h, samples=spp, max_depth=depth, seed=seed)

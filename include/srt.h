@@ -107,7 +107,7 @@ typedef struct {
     uint64_t hit_nodes;      /* GetRayColor calls that hit a surface */
     uint64_t box_tests;      /* BVH nodes whose box was tested   (only filled by srt_render_counted) */
     uint64_t sphere_tests, tri_tests, rect_tests;   /* (only filled by srt_render_counted) */
-    double   kernel_ms;      /* duration of the last trace kernel, from HIP events on its stream */
+    double   kernel_ms;      /* device time of the last render (its trace and resolve kernels), from HIP events on its stream */
     double   build_ms;       /* host time of the last srt_commit_scene (BVH build + upload) */
     uint32_t bvh_nodes;      /* nodes of the committed tree: 32 bytes each (reference tree) or 64 (the library's 4-wide tree) */
     uint32_t bvh_depth;

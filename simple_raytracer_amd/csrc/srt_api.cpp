@@ -87,7 +87,7 @@ SceneView scene_view(const srt_ctx* c)
 }
 
 // Fetches (and zeroes) the counters accumulated by the launches since the last collection, once
-// the most recent launch has finished.  kernel_ms is the duration of that most recent launch.
+// the most recent render has finished.  kernel_ms is the device time of that render (all its passes).
 int collect_stats(srt_ctx* c)
 {
     if (!c->stats_pending) return SRT_OK;

@@ -171,6 +171,15 @@ int  srt_render_counted(srt_ctx* ctx, const srt_render_params* p, uint32_t* rgba
 int  srt_render_async(srt_ctx* ctx, const srt_render_params* p, uint32_t* rgba_out);
 int  srt_poll(srt_ctx* ctx, int* done);
 int  srt_wait(srt_ctx* ctx);
+/* The picture filling in while it renders (Game1.Update uploads the shared Color[] every frame while the worker
+ * threads write it, Game1.cs:188-201): like srt_render_async, but the samples are traced in at least `passes`
+ * (1..64) passes and after each one a preview of the picture so far -- the running sums scaled by samples / samples
+ * done -- is copied to host memory.  srt_progress reports how many passes have finished; srt_read_preview copies the
+ * newest preview (it may mix two consecutive passes if the next copy is landing) and needs at least one finished
+ * pass.  srt_poll / srt_wait complete the render as usual; the final frame is the one srt_render gives. */
+int  srt_render_progressive(srt_ctx* ctx, const srt_render_params* p, uint32_t* rgba_out, int passes);
+int  srt_progress(srt_ctx* ctx, int* passes_done, int* passes_total);
+int  srt_read_preview(srt_ctx* ctx, uint32_t* rgba_out);
 
 /* Counters of the renders since the previous collection (a blocking render collects, so after srt_render
  * these are that render's counters).  Waits for the most recent launch. */

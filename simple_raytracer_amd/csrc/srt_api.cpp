@@ -43,6 +43,10 @@ struct srt_ctx {
     uint32_t* async_dst = nullptr;
     size_t async_pixels = 0;
     bool async_pending = false;
+    // progressive render: one event per pass, recorded after the pass's preview reached pinned memory
+    enum { MAX_PASSES = 64 };
+    hipEvent_t pass_done[MAX_PASSES] = {};
+    int passes_total = 0;
     std::string error;
 };
 
@@ -107,7 +111,9 @@ int collect_stats(srt_ctx* c)
     return SRT_OK;
 }
 
-int launch(srt_ctx* c, const srt_render_params* p, uint32_t* d_out, size_t capacity, hipStream_t stream, bool counted)
+// min_passes > 1 (progressive renders): at least that many passes, each followed by a preview in d_out, a copy of it
+// to pinned memory and an event.
+int launch(srt_ctx* c, const srt_render_params* p, uint32_t* d_out, size_t capacity, hipStream_t stream, bool counted, int min_passes = 1)
 {
     if (!c->committed) return fail(c, SRT_E_STATE, "srt_commit_scene has not been called");
     if (!c->has_camera) return fail(c, SRT_E_STATE, "srt_set_camera has not been called");
@@ -128,6 +134,18 @@ int launch(srt_ctx* c, const srt_render_params* p, uint32_t* d_out, size_t capac
     uint64_t per_pass = fit < by_items ? fit : by_items;
     if (per_pass < 1) per_pass = 1;
     if (per_pass > (uint64_t)ra.samples) per_pass = (uint64_t)ra.samples;
+    const bool progressive = min_passes > 1;
+    if (progressive) {
+        uint64_t share = ((uint64_t)ra.samples + (uint64_t)min_passes - 1) / (uint64_t)min_passes;
+        if (share < 1) share = 1;
+        if (per_pass > share) per_pass = share;
+        // never more passes than events: later passes grow instead
+        uint64_t floor_pp = ((uint64_t)ra.samples + srt_ctx::MAX_PASSES - 1) / srt_ctx::MAX_PASSES;
+        if (per_pass < floor_pp) {
+            if (floor_pp * per_sample > c->sample_budget) return fail(c, SRT_E_LIMIT, "a progressive render of this size needs more than 64 passes");
+            per_pass = floor_pp;
+        }
+    }
     if ((uint64_t)ra.n_work > (((uint64_t)1 << 31) - 1)) return fail(c, SRT_E_LIMIT, "more than 2^31 pixels per rank");
     size_t need_samples = (size_t)(per_pass * per_sample);
     if (need_samples > c->samples_capacity) {
@@ -148,15 +166,24 @@ int launch(srt_ctx* c, const srt_render_params* p, uint32_t* d_out, size_t capac
     }
     SRT_HIP(c, hipEventRecord(c->ev_begin, stream));
     const SceneView view = scene_view(c);
-    for (uint32_t s0 = 0; s0 < (uint32_t)ra.samples; s0 += (uint32_t)per_pass) {
+    int pass = 0;
+    for (uint32_t s0 = 0; s0 < (uint32_t)ra.samples; s0 += (uint32_t)per_pass, pass++) {
         ra.sample_first = s0;
         ra.sample_count = (uint32_t)ra.samples - s0 < (uint32_t)per_pass ? (uint32_t)ra.samples - s0 : (uint32_t)per_pass;
         ra.n_items = ra.n_work * ra.sample_count;
         hipError_t e = launch_trace(view, ra, c->world_kind == SRT_WORLD_BVHNODE, counted, c->d_samples, c->d_stats, c->d_counter, stream);
         if (e != hipSuccess) return hip_fail(c, e, "trace kernel launch");
-        e = launch_resolve(ra, c->d_samples, c->d_running, d_out, s0 == 0, s0 + ra.sample_count >= (uint32_t)ra.samples, stream);
+        const uint32_t done = s0 + ra.sample_count;
+        const float preview = progressive ? (float)ra.samples / (float)done : 0.0f;
+        e = launch_resolve(ra, c->d_samples, c->d_running, d_out, s0 == 0, done >= (uint32_t)ra.samples, preview, stream);
         if (e != hipSuccess) return hip_fail(c, e, "resolve kernel launch");
+        if (progressive) {
+            SRT_HIP(c, hipMemcpyAsync(c->h_pinned, d_out, (size_t)need * sizeof(uint32_t), hipMemcpyDeviceToHost, stream));
+            if (!c->pass_done[pass]) SRT_HIP(c, hipEventCreateWithFlags(&c->pass_done[pass], hipEventDisableTiming));
+            SRT_HIP(c, hipEventRecord(c->pass_done[pass], stream));
+        }
     }
+    c->passes_total = progressive ? pass : 0;
     SRT_HIP(c, hipEventRecord(c->ev_end, stream));
     c->stats_pending = true;
     return SRT_OK;
@@ -244,6 +271,7 @@ void srt_destroy(srt_ctx* c)
     if (c->d_samples) hipFree(c->d_samples);
     if (c->d_running) hipFree(c->d_running);
     if (c->h_pinned) hipHostFree(c->h_pinned);
+    for (hipEvent_t e : c->pass_done) if (e) hipEventDestroy(e);
     if (c->ev_begin) hipEventDestroy(c->ev_begin);
     if (c->ev_end) hipEventDestroy(c->ev_end);
     if (c->stream) hipStreamDestroy(c->stream);
@@ -332,7 +360,7 @@ int srt_render_device(srt_ctx* c, const srt_render_params* p, void* d_rgba_out, 
     return launch(c, p, (uint32_t*)d_rgba_out, capacity_pixels, (hipStream_t)hip_stream, false);
 }
 
-int srt_render_async(srt_ctx* c, const srt_render_params* p, uint32_t* rgba_out)
+static int start_async(srt_ctx* c, const srt_render_params* p, uint32_t* rgba_out, int passes)
 {
     if (!c) return SRT_E_INVALID;
     if (!rgba_out) return fail(c, SRT_E_INVALID, "rgba_out is NULL");
@@ -348,13 +376,43 @@ int srt_render_async(srt_ctx* c, const srt_render_params* p, uint32_t* rgba_out)
         SRT_HIP(c, hipHostMalloc((void**)&c->h_pinned, (size_t)n * sizeof(uint32_t), hipHostMallocDefault));
         c->pinned_capacity = (size_t)n;
     }
-    rc = launch(c, p, c->d_out, c->out_capacity, c->stream, false);
+    rc = launch(c, p, c->d_out, c->out_capacity, c->stream, false, passes);
     if (rc != SRT_OK) return rc;
-    // ev_end marks the end of the kernel; the copy to pinned memory follows it on the same stream
-    SRT_HIP(c, hipMemcpyAsync(c->h_pinned, c->d_out, (size_t)n * sizeof(uint32_t), hipMemcpyDeviceToHost, c->stream));
+    // ev_end marks the end of the kernels; the copy to pinned memory follows it on the same stream (a progressive
+    // render has already queued that copy after its last pass)
+    if (c->passes_total == 0) SRT_HIP(c, hipMemcpyAsync(c->h_pinned, c->d_out, (size_t)n * sizeof(uint32_t), hipMemcpyDeviceToHost, c->stream));
     c->async_dst = rgba_out;
     c->async_pixels = (size_t)n;
     c->async_pending = true;
+    return SRT_OK;
+}
+
+int srt_render_async(srt_ctx* c, const srt_render_params* p, uint32_t* rgba_out) { return start_async(c, p, rgba_out, 1); }
+
+int srt_render_progressive(srt_ctx* c, const srt_render_params* p, uint32_t* rgba_out, int passes)
+{
+    if (c && (passes < 1 || passes > srt_ctx::MAX_PASSES)) return fail(c, SRT_E_INVALID, "passes must be 1..64");
+    return start_async(c, p, rgba_out, passes);
+}
+
+int srt_progress(srt_ctx* c, int* passes_done, int* passes_total)
+{
+    if (!c) return SRT_E_INVALID;
+    if (!passes_done || !passes_total) return fail(c, SRT_E_INVALID, "output pointer is NULL");
+    *passes_total = c->passes_total;
+    int n = 0;
+    while (n < c->passes_total && hipEventQuery(c->pass_done[n]) == hipSuccess) n++;
+    *passes_done = n;
+    return SRT_OK;
+}
+
+int srt_read_preview(srt_ctx* c, uint32_t* rgba_out)
+{
+    if (!c) return SRT_E_INVALID;
+    if (!rgba_out) return fail(c, SRT_E_INVALID, "rgba_out is NULL");
+    if (!c->async_pending || c->passes_total == 0) return fail(c, SRT_E_STATE, "no progressive render is in flight");
+    if (hipEventQuery(c->pass_done[0]) != hipSuccess) return fail(c, SRT_E_STATE, "no pass has finished yet");
+    std::memcpy(rgba_out, c->h_pinned, c->async_pixels * sizeof(uint32_t));
     return SRT_OK;
 }
 

@@ -373,22 +373,26 @@ __global__ void __launch_bounds__(kBlock, SRT_WAVES_PER_SIMD_MESH) mesh_trace_ke
 }
 
 // One thread per pixel of this rank: adds the pass's samples in index order to the running sum
-// (Game1.cs:295) and, after the last pass, applies gamma and packs (Game1.cs:301-306).
+// (Game1.cs:295) and, after the last pass, applies gamma and packs (Game1.cs:301-306).  preview_scale > 0 on an
+// earlier pass also writes a preview of the picture so far: the running sum scaled by samples / samples done.
 __global__ void __launch_bounds__(kBlock) resolve_kernel(RenderArgs ra, const f3* __restrict__ samples, f3* __restrict__ running,
-                                                         uint32_t* __restrict__ out, int first_pass, int last_pass)
+                                                         uint32_t* __restrict__ out, int first_pass, int last_pass, float preview_scale)
 {
     uint32_t wp = blockIdx.x * (uint32_t)kBlock + threadIdx.x;
     if (wp >= ra.n_work) return;
     int32_t x, y;
     uint32_t oi;
     if (!work_to_pixel(ra, wp, x, y, oi)) {
-        if (ra.layout != 0 && last_pass) out[oi] = 0u;  // padding pixel of an edge tile
+        if (ra.layout != 0 && (last_pass || preview_scale > 0.0f)) out[oi] = 0u;  // padding pixel of an edge tile
         return;
     }
     f3 acc = first_pass ? mk3(0.0f, 0.0f, 0.0f) : running[wp];
     acc = accumulate_samples(acc, samples, ra.n_work, wp, ra.sample_count, 1.0f / (float)ra.samples);
     if (last_pass) out[oi] = finish_color(acc);
-    else running[wp] = acc;
+    else {
+        running[wp] = acc;
+        if (preview_scale > 0.0f) out[oi] = finish_color(mk3(acc.x * preview_scale, acc.y * preview_scale, acc.z * preview_scale));
+    }
 }
 
 // Rank 0 of a multi-GPU job: pixel (x, y) of the frame lives in tile t = tx + ty*tiles_x, which
@@ -447,12 +451,12 @@ hipError_t launch_trace(const SceneView& sc, const RenderArgs& ra, bool exact, b
 }
 
 hipError_t launch_resolve(const RenderArgs& ra, const float* d_samples, float* d_running, uint32_t* d_out, bool first_pass, bool last_pass,
-                          hipStream_t stream)
+                          float preview_scale, hipStream_t stream)
 {
     if (ra.n_work == 0u) return hipSuccess;
     dim3 grid((ra.n_work + kBlock - 1) / kBlock), block(kBlock);
     hipLaunchKernelGGL(resolve_kernel, grid, block, 0, stream, ra, reinterpret_cast<const f3*>(d_samples), reinterpret_cast<f3*>(d_running),
-                       d_out, first_pass ? 1 : 0, last_pass ? 1 : 0);
+                       d_out, first_pass ? 1 : 0, last_pass ? 1 : 0, preview_scale);
     return hipGetLastError();
 }
 

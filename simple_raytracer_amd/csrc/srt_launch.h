@@ -15,9 +15,10 @@ namespace srt {
 hipError_t launch_trace(const SceneView& sc, const RenderArgs& ra, bool exact, bool counted, float* d_samples,
                         unsigned long long* d_stats, uint32_t* d_work_counter, hipStream_t stream);
 // Adds the pass's samples to the per-pixel running sums (3 floats per pixel; untouched when the pass is both the
-// first and the last) and, on the last pass, writes the packed pixels.
+// first and the last) and, on the last pass, writes the packed pixels.  preview_scale > 0: earlier passes write a
+// preview (running sum times preview_scale) to d_out as well.
 hipError_t launch_resolve(const RenderArgs& ra, const float* d_samples, float* d_running, uint32_t* d_out, bool first_pass, bool last_pass,
-                          hipStream_t stream);
+                          float preview_scale, hipStream_t stream);
 hipError_t launch_assemble(const RenderArgs& ra, const uint32_t* d_gathered, size_t stride, uint32_t* d_frame, hipStream_t stream);
 
 }  // namespace srt

@@ -110,6 +110,18 @@ class Renderer:
     def render_async(self, p, out):
         self._check(self._lib.srt_render_async(self._ctx, C.byref(p), out.ctypes.data_as(C.c_void_p)))
 
+    def render_progressive(self, p, out, passes):
+        """Like render_async, in at least `passes` passes with a preview after each (Game1.Update's live picture)."""
+        self._check(self._lib.srt_render_progressive(self._ctx, C.byref(p), out.ctypes.data_as(C.c_void_p), int(passes)))
+
+    def progress(self):
+        done, total = C.c_int(0), C.c_int(0)
+        self._check(self._lib.srt_progress(self._ctx, C.byref(done), C.byref(total)))
+        return done.value, total.value
+
+    def read_preview(self, out):
+        self._check(self._lib.srt_read_preview(self._ctx, out.ctypes.data_as(C.c_void_p)))
+
     def poll(self):
         done = C.c_int(0)
         self._check(self._lib.srt_poll(self._ctx, C.byref(done)))

@@ -211,3 +211,42 @@ import random_scenes  # noqa: E402
 def test_gpu_random_scene_matches_oracle(gpu, oracle, seed):
     lsb, npx, same_counts, what = random_scenes.run(gpu, oracle, seed)
     assert lsb <= 1 and same_counts, (lsb, npx, what)
+
+
+def test_gpu_progressive_render(gpu):
+    """The picture fills in while it renders: previews after each pass, the final frame unchanged."""
+    w, h, spp = 320, 180, 24
+    world, lights, cam = helpers.default_spec().host(w, h)
+    gpu.set_scene(world, lights, cam)
+    want = gpu.render(w, h, samples=spp, max_depth=6, seed=3)
+    first_third = gpu.render(w, h, samples=8, max_depth=6, seed=3)     # what the first of three passes has seen
+    p = gpu.params(w, h, samples=spp, max_depth=6, seed=3)
+    out = np.zeros(w * h, dtype=np.uint32)
+    preview = np.zeros(w * h, dtype=np.uint32)
+    with pytest.raises(srt.SrtError):
+        gpu.render_progressive(p, out, 0)
+    gpu.render_progressive(p, out, 3)
+    seen = set()
+    polls = 0
+    while True:
+        done, total = gpu.progress()
+        assert total == 3 and 0 <= done <= 3
+        if done >= 1 and done not in seen:
+            gpu.read_preview(preview)
+            seen.add(done)
+            assert (preview >> 24 == 255).all()          # a complete picture, every pixel written
+        if gpu.poll():
+            break
+        polls += 1
+        assert polls < 10_000_000
+    assert (out.reshape(h, w) == want).all()
+    assert gpu.progress() == (3, 3)
+    # deterministic look at the first preview: a progressive render whose first pass is the whole render of 8 samples
+    # scaled by 24 / 8 and back -- within rounding of the 8-sample picture
+    p8 = gpu.params(w, h, samples=8, max_depth=6, seed=3)
+    gpu.render_progressive(p8, out, 1)      # one pass: same as render_async
+    gpu.wait()
+    assert (out.reshape(h, w) == first_third).all()
+    # blocking renders afterwards are not progressive
+    assert (gpu.render(w, h, samples=spp, max_depth=6, seed=3) == want).all()
+    assert gpu.progress() == (0, 0)

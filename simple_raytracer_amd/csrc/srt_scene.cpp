@@ -427,7 +427,13 @@ struct WideBuilder {
                     if (hi > 255 || decode(u.mn[k], (uint32_t)be, (uint32_t)lo) > b.mn[k]) { fits = false; break; }
                     qlo[k][i] = (uint32_t)lo; qhi[k][i] = (uint32_t)hi;
                 }
-                if (fits || be >= 254) break;            // a coarser grid always fits eventually
+                if (fits) break;
+                if (be >= 254) {
+                    // boxes that are not finite numbers cannot be put on a grid: every child spans the whole cell range
+                    // (for a NaN origin the decoded planes are NaN, which the slab test never culls on)
+                    for (uint32_t i = 0; i < nk; i++) { qlo[k][i] = 0; qhi[k][i] = 255; }
+                    break;
+                }
             }
             e[k] = (uint32_t)be;
             for (uint32_t i = nk; i < 4; i++) { qlo[k][i] = 0; qhi[k][i] = 0; }

@@ -185,7 +185,7 @@ SRT_HD f3 random_hemisphere_vector(const RngKey& k, f3 normal, const float* unit
 enum : uint32_t { PRIM_TRI = 0u, PRIM_SPHERE = 1u, PRIM_RECT = 2u };
 enum : uint32_t { INFO_FLIP = 4u, INFO_BLEND = 8u };
 enum : uint32_t { DESC_LEAF = 0x80000000u, NO_PRIM = 0xFFFFFFFFu };
-enum { STACK_DEPTH = 32, MAX_LEAF_PRIMS = 16, FRAME_SLOTS = 16, TINY_TREE_NODES = 64 };
+enum { STACK_DEPTH = 36, MAX_LEAF_PRIMS = 16, FRAME_SLOTS = 16, TINY_TREE_NODES = 64 };
 
 // Primitive record, 3 words (48 bytes):
 //   tri:    (A.x A.y A.z AB.x) (AB.y AB.z AC.x AC.y) (AC.z  info order normal_index)

@@ -171,7 +171,7 @@ struct ReferenceBuilder {
 // Binned SAH builder
 // ---------------------------------------------------------------------------------------
 struct SahBuilder {
-    enum { BINS = 16, LEAF_MAX = 4, DEPTH_LIMIT = STACK_DEPTH - 2 };
+    enum { BINS = 16, LEAF_MAX = 4, DEPTH_LIMIT = 30 };
     const std::vector<Box>& pb;
     std::vector<uint32_t> ids;
     std::vector<float> cx[3];

@@ -88,12 +88,20 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if world != args.gpus:
         raise SystemExit("--gpus %d but WORLD_SIZE=%d: launch with torch.distributed.run --nproc-per-node %d" % (args.gpus, world, args.gpus))
-    torch.cuda.set_device(local_rank)
+    # SRT_BENCH_BACKEND=gloo is a rehearsal mode for boxes with fewer GPUs than ranks (the ranks then share devices and
+    # the tile buffers are gathered through host memory); the measured configuration is nccl = RCCL, one GPU per rank.
+    backend = os.environ.get("SRT_BENCH_BACKEND", "nccl")
+    device_index = local_rank if backend == "nccl" else local_rank % max(1, torch.cuda.device_count())
+    torch.cuda.set_device(device_index)
     if world > 1:
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", device_index))
+        else:
+            dist.init_process_group(backend)
+    reduce_device = "cuda" if backend == "nccl" else "cpu"
 
     spp = SPP_PER_GPU * world
-    r = srt.Renderer(device=local_rank)
+    r = srt.Renderer(device=device_index)
     scene_world, lights, cam = game1.default_scene(WIDTH, HEIGHT)
     kind = srt.WORLD_BVHNODE if args.world_kind == "bvhnode" else srt.WORLD_SURFACELIST
     r.set_scene(scene_world, lights, cam, world_kind=kind)
@@ -144,8 +152,8 @@ def main():
     st = r.stats()     # counters accumulated over the timed launches
     launch_ms = [a.elapsed_time(b) for a, b in events]
 
-    t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
-    rays = torch.tensor([float(st["rays_path"]), float(st["rays_shadow"])], dtype=torch.float64, device="cuda")
+    t = torch.tensor([elapsed], dtype=torch.float64, device=reduce_device)
+    rays = torch.tensor([float(st["rays_path"]), float(st["rays_shadow"])], dtype=torch.float64, device=reduce_device)
     if world > 1:
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dist.all_reduce(rays, op=dist.ReduceOp.SUM)
@@ -185,7 +193,9 @@ def main():
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": "default Game1 scene (5 spheres, 2 point lights), %dx%d, %d spp per GPU (%d total), depth %d, %s world, "
                                    "%s" % (WIDTH, HEIGHT, SPP_PER_GPU, spp, MAX_DEPTH, args.world_kind,
-                                           "single frame buffer" if world == 1 else "32x32 tiles interleaved over ranks + RCCL gather to rank 0"),
+                                           "single frame buffer" if world == 1 else
+                                           ("32x32 tiles interleaved over ranks + RCCL gather to rank 0" if backend == "nccl" else
+                                            "32x32 tiles interleaved over ranks + gloo gather through host memory (REHEARSAL, ranks may share GPUs)")),
                        "width": WIDTH, "height": HEIGHT, "spp": spp, "max_depth": MAX_DEPTH, "seed": 1},
             "rays_per_step": total_rays / args.steps, "shadow_rays_per_step": total_shadow / args.steps,
             "traversals_per_sec_M": round((total_rays + total_shadow) / elapsed / 1e6, 2),

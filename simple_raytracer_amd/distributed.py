@@ -83,6 +83,14 @@ class TiledFrame:
             if self.rank == 0:
                 self.gathered.copy_(self.out)
             return
+        if self.device.type == "cuda" and dist.get_backend(self.group) == "gloo":
+            # rehearsal without RCCL (several ranks sharing one GPU): gloo gathers host tensors only
+            host = self.out.cpu()
+            parts = [torch.empty_like(host) for _ in range(self.world)] if self.rank == 0 else None
+            dist.gather(host, parts, dst=0, group=self.group)
+            if self.rank == 0:
+                self.gathered.view(self.world, self.stride).copy_(torch.stack(parts))
+            return
         dist.gather(self.out, self.gather_list if self.rank == 0 else None, dst=0, group=self.group)
 
     def assemble(self):

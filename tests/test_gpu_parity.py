@@ -250,3 +250,44 @@ def test_gpu_progressive_render(gpu):
     # blocking renders afterwards are not progressive
     assert (gpu.render(w, h, samples=spp, max_depth=6, seed=3) == want).all()
     assert gpu.progress() == (0, 0)
+
+
+DIST_WORKER = """
+import os, sys
+sys.path.insert(0, {root!r}); sys.path.insert(0, os.path.join({root!r}, "tests"))
+import numpy as np, torch, torch.distributed as dist
+import helpers, simple_raytracer_amd as srt
+from simple_raytracer_amd.distributed import TiledFrame
+dist.init_process_group("gloo")
+rank, world = dist.get_rank(), dist.get_world_size()
+torch.cuda.set_device(0)
+w, h = 330, 190
+spec = helpers.default_spec()
+world_s, lights, cam = spec.host(w, h)
+r = srt.Renderer(device=0)
+r.set_scene(world_s, lights, cam, world_kind=srt.WORLD_BVHNODE)
+tf = TiledFrame(r, w, h, tile=32, device="cuda", samples=3, max_depth=6, seed=5)
+for _ in range(2):
+    frame = tf.step()
+torch.cuda.synchronize()
+if rank == 0:
+    want = r.render(w, h, samples=3, max_depth=6, seed=5)
+    img = frame.cpu().numpy().view(np.uint32).reshape(h, w)
+    assert (img == want).all(), "assembled frame differs from the single-process frame"
+    print("GPU-DIST-OK", world)
+dist.barrier()
+dist.destroy_process_group()
+"""
+
+
+def test_gpu_three_ranks_share_the_device(tmp_path):
+    """The multi-GPU path with real device buffers, the assemble kernel and one process per rank; the ranks share
+    this box's one GPU and gather through host memory (gloo), since RCCL needs one GPU per rank."""
+    import subprocess
+    import sys
+    script = tmp_path / "worker.py"
+    script.write_text(DIST_WORKER.format(root=helpers.ROOT))
+    out = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "3", "--master-addr", "127.0.0.1",
+                          "--master-port", "29541", str(script)], capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-4000:]
+    assert "GPU-DIST-OK 3" in out.stdout

@@ -491,10 +491,12 @@ SRT_HD void trav_run(const SceneView& sc, f3 o, float t_min, Trav& tr, uint32_t*
                 uint32_t lx = fbits(w1.x), ly = fbits(w1.y), lz = fbits(w1.z), hx = fbits(w1.w), hy = fbits(w2.x), hz = fbits(w2.y);
                 uint32_t nx = bx ? hx : lx, fx = bx ? lx : hx, ny = by ? hy : ly, fy = by ? ly : hy, nz = bz ? hz : lz, fz = bz ? lz : hz;
                 uint32_t c0 = fbits(w2.z), c1 = fbits(w2.w), c2 = fbits(w3.x), c3 = fbits(w3.y);
+                // all four slots are evaluated (no branch on the child count); unused slots are masked afterwards
                 float t0 = wide_child(nx, ny, nz, fx, fy, fz, 0, A, B, best.t);
-                float t1 = nk > 1u ? wide_child(nx, ny, nz, fx, fy, fz, 8, A, B, best.t) : INFINITY;
-                float t2 = nk > 2u ? wide_child(nx, ny, nz, fx, fy, fz, 16, A, B, best.t) : INFINITY;
-                float t3 = nk > 3u ? wide_child(nx, ny, nz, fx, fy, fz, 24, A, B, best.t) : INFINITY;
+                float t1 = wide_child(nx, ny, nz, fx, fy, fz, 8, A, B, best.t);
+                float t2 = wide_child(nx, ny, nz, fx, fy, fz, 16, A, B, best.t);
+                float t3 = wide_child(nx, ny, nz, fx, fy, fz, 24, A, B, best.t);
+                t1 = nk > 1u ? t1 : INFINITY; t2 = nk > 2u ? t2 : INFINITY; t3 = nk > 3u ? t3 : INFINITY;
                 sort_pair(t0, c0, t1, c1); sort_pair(t2, c2, t3, c3);
                 sort_pair(t0, c0, t2, c2); sort_pair(t1, c1, t3, c3);
                 sort_pair(t1, c1, t2, c2);

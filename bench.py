@@ -3,7 +3,7 @@
 
     python bench.py --gpus N --steps K --warmup W        (N > 1: launched by torch.distributed.run, one rank per GPU)
 
-A step is one frame of the workload BASELINE.json's metric is quoted on -- the default Game1 scene (Game1.cs:96-144)
+A step is one frame of the headline workload -- the default Game1 scene (Game1.cs:96-144)
 at 1920x1080, depth 8, traced as the reference does (GetRayColor on the BVHNode world, Game1.cs:293) -- with 16
 samples per pixel PER GPU (weak scaling: N GPUs render 16*N spp; the frame is split into 32x32 screen tiles
 interleaved over the ranks, each rank traces its tiles, the tile buffers are gathered on rank 0 over RCCL and

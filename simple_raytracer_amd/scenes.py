@@ -1,4 +1,4 @@
-"""Synthetic scenes for the mesh configurations of BASELINE.json (the reference ships only two small meshes,
+"""Synthetic scenes for the mesh benchmark configurations (the reference ships only two small meshes,
 Content/models/teapot.dae with 6,320 triangles and sphere.dae with 960; the ~100k and ~1M triangle inputs are made
 from them by midpoint subdivision)."""
 import os
@@ -48,7 +48,7 @@ def _default_lights():
 
 
 def teapot_scene(width, height, levels=2):
-    """BASELINE config 3: teapot.dae subdivided `levels` times (2 -> 101,120 triangles), material mat6 (Game1.cs:109),
+    """The 100k-triangle mesh configuration: teapot.dae subdivided `levels` times (2 -> 101,120 triangles), material mat6 (Game1.cs:109),
     the loader's fallback camera (fov 29, ModelLoader.cs:105) pulled back to frame the model, the two default lights."""
     p, n = subdivide(*load_fixture_mesh("teapot"), levels=levels)
     mat6 = game1.materials()[5]
@@ -60,7 +60,7 @@ def teapot_scene(width, height, levels=2):
 
 
 def sphere_mesh_scene(width, height, levels=5, n_spheres=0, seed=42):
-    """BASELINE configs 4 / 5: sphere.dae subdivided `levels` times (5 -> 983,040 triangles), scaled by 10 and centred at
+    """The 1M-triangle configurations: sphere.dae subdivided `levels` times (5 -> 983,040 triangles), scaled by 10 and centred at
     (0, 0, -30); optionally `n_spheres` random metal/rough spheres around it (config 4: 10,000).  Camera at the origin."""
     p, n = subdivide(*load_fixture_mesh("sphere"), levels=levels)
     p = (p.reshape(-1, 3) * np.float32(10.0) + np.array([0, 0, -30], dtype=np.float32)).reshape(-1, 9)

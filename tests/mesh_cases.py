@@ -24,7 +24,7 @@ def teapot_with_spheres(width, height, n_spheres=40):
 
 
 def sphere_mesh(width, height, levels=1):
-    """sphere.dae subdivided once (3,840 triangles), camera inside the frame of BASELINE config 5."""
+    """sphere.dae subdivided once (3,840 triangles), framed like the 1M-triangle benchmark scene."""
     return scenes.sphere_mesh_scene(width, height, levels=levels)
 
 

@@ -131,8 +131,8 @@ def test_gpu_device_render_and_assemble(gpu, oracle):
     assert lsb <= 1, (lsb, npx)
 
 
-# ---- BASELINE sizes: properties that need no full-size oracle render ---------------------------------------------------
-FULL = dict(width=1920, height=1080, samples=16, max_depth=8)   # BASELINE config 2
+# ---- benchmark size: properties that need no full-size oracle render ---------------------------------------------------
+FULL = dict(width=1920, height=1080, samples=16, max_depth=8)   # the headline configuration
 
 
 def test_gpu_full_size_window_parity_and_invariants(gpu, oracle):

@@ -1,4 +1,4 @@
-"""Measures the mesh configurations of BASELINE.json on one GPU (not the bench contract's line: bench.py stays on config 2).
+"""Measures the mesh benchmark configurations on one GPU (bench.py stays on the sphere scene).
 
     python tools/big_scenes.py [c3] [c5] [c4] [--spp N] [--cpu]
 

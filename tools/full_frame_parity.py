@@ -1,4 +1,4 @@
-"""One-off check behind a number in DESIGN.md: the whole bench frame (Game1 scene, 1920x1080, 16 spp, depth 8) from the GPU
+"""One-off check: the whole bench frame (Game1 scene, 1920x1080, 16 spp, depth 8) from the GPU
 against the CPU oracle, both world kinds.  Takes about 40 s of CPU time on 16 threads.
 
     python tools/full_frame_parity.py

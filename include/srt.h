@@ -119,7 +119,8 @@ typedef struct {
     /* Shader-clock cycles summed over wavefronts (only filled by srt_render_counted), by part of the kernel:
        0 dealing work items, 1 handing values up the tree, 2 closest-hit query, 3 bookkeeping after it,
        4 random words of a lit node, 5 shadow-ray set-up, 6 shadow query, 7 light evaluation,
-       8 child directions, 9 fresnel, 10 starting a child / finishing a leaf; 11-15 unused. */
+       8 child directions, 9 fresnel, 10 starting a child / finishing a leaf; 11-14 unused;
+       15 is a count, not cycles: subtrees that lanes handed to idle lanes of their wavefront (mesh scenes). */
     uint64_t section_cycles[16];
 } srt_stats;
 

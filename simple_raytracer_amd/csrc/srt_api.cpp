@@ -30,6 +30,7 @@ struct srt_ctx {
     size_t out_capacity = 0;  // pixels
     unsigned long long* d_stats = nullptr;
     uint32_t* d_counter = nullptr;        // work counter of the persistent trace kernel
+    float* d_mail = nullptr;              // mailboxes of the mesh kernel (subtree colours handed between lanes)
     float* d_samples = nullptr;           // per-(sample, pixel) colours of one pass, 12 bytes each
     size_t samples_capacity = 0;          // bytes
     float* d_running = nullptr;           // per-pixel running sums, only for renders that need several passes
@@ -171,7 +172,7 @@ int launch(srt_ctx* c, const srt_render_params* p, uint32_t* d_out, size_t capac
         ra.sample_first = s0;
         ra.sample_count = (uint32_t)ra.samples - s0 < (uint32_t)per_pass ? (uint32_t)ra.samples - s0 : (uint32_t)per_pass;
         ra.n_items = ra.n_work * ra.sample_count;
-        hipError_t e = launch_trace(view, ra, c->world_kind == SRT_WORLD_BVHNODE, counted, c->d_samples, c->d_stats, c->d_counter, stream);
+        hipError_t e = launch_trace(view, ra, c->world_kind == SRT_WORLD_BVHNODE, counted, c->d_samples, c->d_stats, c->d_counter, c->d_mail, stream);
         if (e != hipSuccess) return hip_fail(c, e, "trace kernel launch");
         const uint32_t done = s0 + ra.sample_count;
         const float preview = progressive ? (float)ra.samples / (float)done : 0.0f;
@@ -246,6 +247,7 @@ int srt_create(const srt_config* cfg, srt_ctx** out)
               hipEventCreate(&c->ev_begin) == hipSuccess && hipEventCreate(&c->ev_end) == hipSuccess &&
               hipMalloc((void**)&c->d_stats, 32 * sizeof(unsigned long long)) == hipSuccess &&
               hipMalloc((void**)&c->d_counter, sizeof(uint32_t)) == hipSuccess &&
+              hipMalloc((void**)&c->d_mail, trace_mail_bytes()) == hipSuccess &&
               hipMemset(c->d_stats, 0, 32 * sizeof(unsigned long long)) == hipSuccess && hipDeviceSynchronize() == hipSuccess;
     if (!ok) {
         srt_destroy(c);
@@ -268,6 +270,7 @@ void srt_destroy(srt_ctx* c)
     if (c->d_out) hipFree(c->d_out);
     if (c->d_stats) hipFree(c->d_stats);
     if (c->d_counter) hipFree(c->d_counter);
+    if (c->d_mail) hipFree(c->d_mail);
     if (c->d_samples) hipFree(c->d_samples);
     if (c->d_running) hipFree(c->d_running);
     if (c->h_pinned) hipHostFree(c->h_pinned);

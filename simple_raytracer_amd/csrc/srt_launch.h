@@ -12,8 +12,10 @@ namespace srt {
 // rank's pixels.  d_samples: 3 floats per (sample, pixel), sample-major, ra.sample_count * ra.n_work entries.
 // d_stats: 32 x uint64 the kernel adds to: rays_path, rays_shadow, hit_nodes, box_tests, sphere_tests,
 // tri_tests, rect_tests, (unused).  d_work_counter: one uint32, reset by the launcher on `stream`.
+// d_mail: trace_mail_bytes() of device memory (or NULL) that the mesh kernel uses to pass subtree colours between lanes.
 hipError_t launch_trace(const SceneView& sc, const RenderArgs& ra, bool exact, bool counted, float* d_samples,
-                        unsigned long long* d_stats, uint32_t* d_work_counter, hipStream_t stream);
+                        unsigned long long* d_stats, uint32_t* d_work_counter, float* d_mail, hipStream_t stream);
+size_t trace_mail_bytes();
 // Adds the pass's samples to the per-pixel running sums (3 floats per pixel; untouched when the pass is both the
 // first and the last) and, on the last pass, writes the packed pixels.  preview_scale > 0: earlier passes write a
 // preview (running sum times preview_scale) to d_out as well.

@@ -11,7 +11,8 @@
 //           RaytracingClasses.cs:205-218) and then the node's shading, which either starts the
 //           first child (back to TRACE) or finds that the node has no children to trace (RETURN);
 //   RETURN  a GetRayColor call has its value (a miss, or a node without traced children): it is handed
-//           up the tree until some parent has another child to start (TRACE) or the sample is done.
+//           up the tree until some parent has another child to start (TRACE) or the sample is done;
+//   WAIT    (mesh kernel only) the next child of a pending node was handed to another lane and is not back yet.
 // The kernel runs the phases as separate, wave-wide code sections, so that lanes which execute a
 // section all execute the same code.
 #ifndef SRT_PATH_H
@@ -21,7 +22,7 @@
 
 namespace srt {
 
-enum { LANE_IDLE = 0, LANE_TRACE = 1, LANE_LIGHT = 2, LANE_RETURN = 3 };
+enum { LANE_IDLE = 0, LANE_TRACE = 1, LANE_LIGHT = 2, LANE_RETURN = 3, LANE_WAIT = 4 };
 
 struct Lane {
     uint32_t slot;      // where the sample's colour goes in the sample buffer
@@ -142,8 +143,19 @@ SRT_HD f3 clamp_color(f3 c, float hi) { return mk3(clampf(c.x, 0.0f, hi), clampf
 // RETURN phase: the GetRayColor call of node ln.key.node returned ln.former: hand it to the parent, start
 // the next child or complete parents up the tree.  Returns LANE_TRACE with a new query, or LANE_IDLE
 // with `ret` holding the colour of the whole sample.
-template <class FRAMES>
-SRT_HD int lane_return(Lane& ln, f3& ret, const SceneView& sc, const RenderArgs& ra, const FRAMES& frames)
+// A kernel may hand children 1 and 2 of one of a lane's pending nodes (one frame at a time) to other lanes: the RNG is
+// keyed by the node id, so a subtree evaluates to the same colour wherever it runs.  `fork.donated(level, child)` says
+// whether that child of the frame at `level` was given away; lane_return then stops with LANE_WAIT after noting the
+// child in fork.wait_for(child), with the sum so far stored in the frame, the frame still on the stack and
+// ln.key.node = the frame's node id.  The kernel resumes the lane in the RETURN phase with ln.key.node = the child's
+// id and ln.former = the child's colour, exactly as if the child had just returned.
+struct NoFork {
+    SRT_HD bool donated(int32_t, uint32_t) const { return false; }
+    SRT_HD void wait_for(uint32_t) const {}
+};
+
+template <class FRAMES, class FORK = NoFork>
+SRT_HD int lane_return(Lane& ln, f3& ret, const SceneView& sc, const RenderArgs& ra, const FRAMES& frames, FORK&& fork = FORK())
 {
     ret = ln.former;
     while (ln.level > 0) {
@@ -170,6 +182,7 @@ SRT_HD int lane_return(Lane& ln, f3& ret, const SceneView& sc, const RenderArgs&
         }
         if (next < 3u) {
             frames.store_acc(ln.level - 1, acc);
+            if (fork.donated(ln.level - 1, next)) { fork.wait_for(next); return LANE_WAIT; }
             lane_begin_child(ln, next, f.point, f.refl, child_depth);
             return LANE_TRACE;
         }

@@ -62,6 +62,8 @@ def main():
                  "child_start"]
         tot = float(sum(cst["section_cycles"])) or 1.0
         line["cycle_share"] = {n: round(c / tot, 3) for n, c in zip(names, cst["section_cycles"])}
+        line["subtrees_handed_over"] = cst["section_cycles"][15]
+        line["walk_quanta"] = cst["trace_sections"]
         line["lanes_per_trace_section"] = round(cst["trace_lanes"] / max(1, cst["trace_sections"]), 1)
         line["lanes_per_light_section"] = round(cst["light_lanes"] / max(1, cst["light_sections"]), 1)
         if "--cpu" in sys.argv:

@@ -291,3 +291,28 @@ def test_gpu_three_ranks_share_the_device(tmp_path):
                           "--master-port", "29541", str(script)], capture_output=True, text=True, timeout=300)
     assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-4000:]
     assert "GPU-DIST-OK 3" in out.stdout
+
+
+def test_gpu_subtree_sharing_keeps_the_image(gpu, oracle):
+    """Deep ray trees (three children per node, depth 8) on a mesh scene: once the work counter is exhausted the mesh
+    kernel's lanes hand subtrees to idle lanes of their wavefront.  The picture and the ray counts must be the oracle's,
+    and the counter of handed-over subtrees shows that the mechanism ran."""
+    spec = helpers.mesh_spec(n=8)
+    rng = np.random.default_rng(3)
+    for i in range(60):          # a cloud of half-metallic spheres: diffuse, metal and reflect child at every hit
+        c = rng.uniform(-3, 3, 3) + np.array([0, 0, -6.0])
+        spec.materials.append((tuple(float(v) for v in rng.uniform(0.3, 1, 3)), 0.5, 0.9, (0, 0, 0)))
+        spec.spheres.append((tuple(float(v) for v in c), float(rng.uniform(0.2, 0.6)), len(spec.materials) - 1))
+    w, h = 96, 54
+    world, lights, cam = spec.host(w, h)
+    gpu.set_scene(world, lights, cam, world_kind=srt.WORLD_SURFACELIST)
+    img = gpu.render(w, h, samples=1, max_depth=8, seed=9, counted=True)
+    st = gpu.stats()
+    ref, ost = spec.oracle_scene().render(spec.oracle_camera(w, h), w, h, samples=1, max_depth=8, seed=9,
+                                          world_kind=oracle.WORLD_SURFACELIST)
+    lsb, npx = helpers.max_lsb_diff(img, ref)
+    assert (lsb, npx) == (0, 0)
+    for k in ("rays_path", "rays_shadow", "hit_nodes"):
+        assert st[k] == ost[k], k
+    assert st["rays_path"] > 8 * w * h           # the trees are deep (1.5 rays per pixel on the plain mesh scene)
+    assert st["section_cycles"][15] > 0          # subtrees were handed over

@@ -65,6 +65,124 @@ struct ClockProf {
     }
 };
 
+// Sharing one ray tree between lanes.  Once the global counter is exhausted, a wavefront whose lanes are partly idle
+// lets busy lanes hand subtrees to the idle ones: a lane gives away child 1 or 2 (the metal / reflect child, whose ray
+// is stored in the frame) of its shallowest pending node, one node at a time.  The helper lane traces the subtree as a
+// work item of its own -- same pixel, sample and node id, hence the same random numbers and the same colour -- and
+// leaves the colour in the giver's mailbox (global memory, two slots per lane); the giver consumes it where it would
+// have started that child (lane_return -> LANE_WAIT -> resumed as RETURN).  Helpers give away parts of their subtrees
+// in turn, so one deep tree (3,280 nodes at depth 8 with three children per node) spreads over the wavefront instead
+// of keeping one lane busy long after everything else has finished.  Results and ray counts do not change.
+struct TreeFork {
+    int32_t level;     // the frame whose children are with other lanes (-1: none)
+    uint32_t bits;     // bit 1 / 2: child 1 / 2 of that frame is with another lane; bits 4-5: the child waited for
+    __device__ __forceinline__ bool donated(int32_t lvl, uint32_t child) const { return lvl == level && ((bits >> child) & 1u) != 0u; }
+    __device__ __forceinline__ void wait_for(uint32_t child) { bits = (bits & 0xFu) | (child << 4); }
+};
+constexpr int kForkEvery = 4;          // look for subtrees to hand over on every kForkEvery-th trip of the main loop
+constexpr int kForkMinDepth = 2;       // only subtrees that can still grow (remaining depth >= this)
+constexpr size_t kMailPerWave = 128;   // float4 entries: [child - 1][lane]
+
+// A lane in LANE_WAIT: has the colour of the child it waits for arrived?  Then it continues in LANE_RETURN as if that
+// child had just returned.
+__device__ __forceinline__ void poll_mailbox(Lane& ln, int& phase, TreeFork& fork, float4* my_mail, uint32_t lane)
+{
+    if (phase != LANE_WAIT) return;
+    const uint32_t c = fork.bits >> 4;
+    float4* slot = &my_mail[(size_t)(c - 1u) * 64 + lane];
+    if (__hip_atomic_load(&slot->w, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) == 1.0f) {
+        ln.former = mk3(__hip_atomic_load(&slot->x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT),
+                        __hip_atomic_load(&slot->y, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT),
+                        __hip_atomic_load(&slot->z, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+        ln.key.node = ln.key.node * 4u + c + 1u;
+        fork.bits &= 0xFu & ~(1u << c);
+        phase = LANE_RETURN;
+    }
+}
+
+// The colour of a finished tree: into the sample buffer, or -- for a subtree traced for another lane -- into that
+// lane's mailbox (colour first, then the flag).
+__device__ __forceinline__ void deliver_colour(const Lane& ln, f3 ret, int32_t& deliver, float4* my_mail, f3* __restrict__ samples)
+{
+    if (deliver >= 0) {
+        float4* slot = &my_mail[(size_t)((deliver >> 8) - 1) * 64 + (size_t)(deliver & 63)];
+        __hip_atomic_store(&slot->x, ret.x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_store(&slot->y, ret.y, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_store(&slot->z, ret.z, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_store(&slot->w, 1.0f, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+        deliver = -1;
+    } else {
+        samples[ln.slot] = ret;
+    }
+}
+
+// Wave-wide: pairs lanes that can give a subtree away with idle lanes.  Returns true on the lanes that took one; their
+// Lane then holds the subtree's root query (key, qo, qd, qtmin, depth, level 0) and `deliver` says where its colour
+// goes.  Phases are the LANE_* values (idle lanes are LANE_IDLE, waiting lanes LANE_WAIT).
+template <class FRAMES>
+__device__ __forceinline__ bool share_subtrees(Lane& ln, int phase, const FRAMES& frames, TreeFork& fork, int32_t& deliver, float4* my_mail,
+                                               uint32_t* my_pair, const SceneView& sc, const RenderArgs& ra, uint32_t lane, uint32_t& handed)
+{
+    const unsigned long long idle_mask = __ballot(phase == LANE_IDLE);
+    if (idle_mask == 0ull) return false;
+    bool cand = false;
+    uint32_t g_child = 0u, g_node = 0u;
+    int32_t g_level = 0, g_depth = 0;
+    f3 g_point = mk3(0.0f, 0.0f, 0.0f), g_dir = mk3(0.0f, 0.0f, 0.0f);
+    if (phase != LANE_IDLE && ln.level >= 1) {
+        const bool waiting = phase == LANE_WAIT;
+        // frames to look at: the fork frame if there is one, else all of them from the shallowest
+        int32_t j0 = fork.level >= 0 ? fork.level : 0, j1 = fork.level >= 0 ? fork.level : ln.level - 1;
+        for (int32_t j = j0; j <= j1 && !cand; j++) {
+            const Frame f = frames.load(j);
+            const int32_t child_depth = (int32_t)(f.meta >> 24);
+            if (child_depth < kForkMinDepth) break;      // deeper frames have less depth left still
+            const float metal = sc.materials[2u * (f.meta & 0x00FFFFFFu)].w;
+            // node id of frame j and the child of it that is running (a waiting lane holds the frame's id)
+            const uint32_t node_j = waiting ? ln.key.node : ln.key.node >> (2 * (ln.level - j));
+            const uint32_t running = waiting ? (fork.bits >> 4) : ((ln.key.node >> (2 * (ln.level - 1 - j))) & 3u) - 1u;
+            for (uint32_t c = 2u; c >= 1u && !cand; c--) {
+                const bool exists = c == 1u ? (metal != 0.0f) : (metal != 1.0f);
+                const bool given = j == fork.level && ((fork.bits >> c) & 1u) != 0u;
+                if (c > running && exists && !given) {
+                    cand = true; g_child = c; g_node = node_j; g_level = j; g_depth = child_depth; g_point = f.point; g_dir = f.refl;
+                }
+            }
+        }
+    }
+    const unsigned long long cand_mask = __ballot(cand);
+    const uint32_t n_cand = (uint32_t)__popcll(cand_mask), n_idle = (uint32_t)__popcll(idle_mask);
+    const uint32_t n_pairs = n_cand < n_idle ? n_cand : n_idle;
+    if (n_pairs == 0u) return false;
+    handed += n_pairs;
+    const uint32_t rank_c = lanes_below(cand_mask), rank_i = lanes_below(idle_mask);
+    const bool gives = cand && rank_c < n_pairs, takes = phase == LANE_IDLE && rank_i < n_pairs;
+    if (gives) my_pair[rank_c] = lane;
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    const int src = takes ? (int)my_pair[rank_i] : (int)lane;
+    const uint32_t s_pixel = (uint32_t)__shfl((int)ln.key.pixel, src, 64), s_sample = (uint32_t)__shfl((int)ln.key.sample, src, 64);
+    const uint32_t s_node = (uint32_t)__shfl((int)g_node, src, 64), s_child = (uint32_t)__shfl((int)g_child, src, 64);
+    const int32_t s_depth = __shfl(g_depth, src, 64);
+    const f3 s_point = mk3(__shfl(g_point.x, src, 64), __shfl(g_point.y, src, 64), __shfl(g_point.z, src, 64));
+    const f3 s_dir = mk3(__shfl(g_dir.x, src, 64), __shfl(g_dir.y, src, 64), __shfl(g_dir.z, src, 64));
+    if (gives) {
+        fork.level = g_level;
+        fork.bits |= 1u << g_child;
+        __hip_atomic_store(&my_mail[(size_t)(g_child - 1u) * 64 + lane].w, 0.0f, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    if (takes) {
+        ln.key.seed = ra.seed; ln.key.pixel = s_pixel; ln.key.sample = s_sample;
+        ln.key.node = s_node * 4u + s_child + 1u;
+        ln.qo = s_point; ln.qd = s_dir; ln.qtmin = 0.01f;
+        ln.depth = s_depth; ln.level = 0;
+        fork.level = -1; fork.bits = 0u;
+        deliver = src | (int32_t)(s_child << 8);
+    }
+    return takes;
+}
+
 // SMALL kernels serve scenes that need no traversal stack (a reference tree of a few nodes, walked with the
 // wave-uniform loop, or a handful of surfaces scanned linearly) and whose primitive and material tables fit the
 // limits below.  Their LDS holds those two tables (they are indexed per lane) and the first kLdsFrameLevels
@@ -225,25 +343,8 @@ __global__ void __launch_bounds__(kBlock, SMALL ? SRT_WAVES_PER_SIMD : SRT_WAVES
 // are best: 34.2 / 32.6 / 34.8 / 39.5 ms for 1 / 2 / 3 / 6).  So the defaults never split a traversal; what pays is one copy of the
 // traversal code for both kinds of query, short descents between leaf tests, and starting traversals in batches.
 enum { MESH_IDLE = 0, MESH_CLOSEST = 1, MESH_SHADOW = 2, MESH_RETURN = 3, MESH_WAIT = 4 };
+static_assert(MESH_IDLE == LANE_IDLE && MESH_RETURN == LANE_RETURN && MESH_WAIT == LANE_WAIT, "the subtree-sharing helpers take either kernel's phases");
 constexpr int kWalkVote = 16, kWalkRounds = 1 << 24, kWalkSteps = 2;
-
-// Sharing one ray tree between lanes.  Once the global counter is exhausted, a wavefront whose lanes are partly idle
-// lets busy lanes hand subtrees to the idle ones: a lane gives away child 1 or 2 (the metal / reflect child, whose ray
-// is stored in the frame) of its shallowest pending node, one node at a time.  The helper lane traces the subtree as a
-// work item of its own -- same pixel, sample and node id, hence the same random numbers and the same colour -- and
-// leaves the colour in the giver's mailbox (global memory, two slots per lane); the giver consumes it where it would
-// have started that child (lane_return -> LANE_WAIT -> resumed as RETURN).  Helpers give away parts of their subtrees
-// in turn, so one deep tree (3,280 nodes at depth 8) spreads over the wavefront instead of keeping one lane busy for
-// a third of a second after everything else has finished.  Results and ray counts do not change.
-struct MeshFork {
-    int32_t level;     // the frame whose children are with other lanes (-1: none)
-    uint32_t bits;     // bit 1 / 2: child 1 / 2 of that frame is with another lane; bits 4-5: the child waited for
-    __device__ __forceinline__ bool donated(int32_t lvl, uint32_t child) const { return lvl == level && ((bits >> child) & 1u) != 0u; }
-    __device__ __forceinline__ void wait_for(uint32_t child) { bits = (bits & 0xFu) | (child << 4); }
-};
-constexpr int kForkEvery = 4;          // look for subtrees to hand over on every kForkEvery-th trip of the main loop
-constexpr int kForkMinDepth = 2;       // only subtrees that can still grow (remaining depth >= this)
-constexpr size_t kMailPerWave = 128;   // float4 entries: [child - 1][lane]
 
 template <bool EXACT, bool COUNT>
 __global__ void __launch_bounds__(kBlock, SRT_WAVES_PER_SIMD_MESH) mesh_trace_kernel(SceneView sc, RenderArgs ra, f3* __restrict__ samples,
@@ -272,7 +373,7 @@ __global__ void __launch_bounds__(kBlock, SRT_WAVES_PER_SIMD_MESH) mesh_trace_ke
     ln.rays_path = ln.rays_shadow = ln.hit_nodes = 0u;
     ln.level = 0; ln.key.node = 0u;
     int phase = MESH_IDLE;
-    MeshFork fork;
+    TreeFork fork;
     fork.level = -1; fork.bits = 0u;
     int32_t deliver = -1;      // >= 0: this lane traces a subtree for lane (deliver & 63), child (deliver >> 8) of its fork frame
     float4* my_mail = mail ? mail + ((size_t)blockIdx.x * kWaves + wave) * kMailPerWave : nullptr;
@@ -287,20 +388,7 @@ __global__ void __launch_bounds__(kBlock, SRT_WAVES_PER_SIMD_MESH) mesh_trace_ke
     // the lane's next state after a per-lane function returned LANE_*; `ret` is the sample's colour for LANE_IDLE
     auto enter = [&](int lane_phase, f3 ret) {
         if (fork.level >= 0 && ln.level <= fork.level) { fork.level = -1; fork.bits = 0u; }   // the fork frame is complete
-        if (lane_phase == LANE_IDLE) {
-            if (deliver >= 0) {
-                // a subtree traced for another lane: colour first, then the flag
-                float4* slot = &my_mail[(size_t)((deliver >> 8) - 1) * 64 + (size_t)(deliver & 63)];
-                __hip_atomic_store(&slot->x, ret.x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                __hip_atomic_store(&slot->y, ret.y, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                __hip_atomic_store(&slot->z, ret.z, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                __hip_atomic_store(&slot->w, 1.0f, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
-                deliver = -1;
-            } else {
-                samples[ln.slot] = ret;
-            }
-            phase = MESH_IDLE;
-        }
+        if (lane_phase == LANE_IDLE) { deliver_colour(ln, ret, deliver, my_mail, samples); phase = MESH_IDLE; }
         else if (lane_phase == LANE_WAIT) phase = MESH_WAIT;
         else if (lane_phase == LANE_RETURN) phase = MESH_RETURN;
         else if (lane_phase == LANE_TRACE) { tr.d = ln.qd; tr.cur = TRAV_NEW; phase = MESH_CLOSEST; }
@@ -316,82 +404,15 @@ __global__ void __launch_bounds__(kBlock, SRT_WAVES_PER_SIMD_MESH) mesh_trace_ke
 
     for (;;) {
         if constexpr (COUNT) prof.start();
-        // ---- subtrees that other lanes traced for this one
-        if (phase == MESH_WAIT) {
-            const uint32_t c = fork.bits >> 4;
-            float4* slot = &my_mail[(size_t)(c - 1u) * 64 + lane];
-            if (__hip_atomic_load(&slot->w, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) == 1.0f) {
-                ln.former = mk3(__hip_atomic_load(&slot->x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT),
-                                __hip_atomic_load(&slot->y, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT),
-                                __hip_atomic_load(&slot->z, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
-                ln.key.node = ln.key.node * 4u + c + 1u;    // as if that child had just returned
-                fork.bits &= 0xFu & ~(1u << c);
-                phase = MESH_RETURN;
-            }
-        }
-        // ---- hand subtrees to idle lanes once there are no new items
+        // ---- subtrees that other lanes traced for this one; subtrees for idle lanes once there are no new items
+        poll_mailbox(ln, phase, fork, my_mail, lane);
         trip++;
         if (my_mail != nullptr && dry && (trip % (uint32_t)kForkEvery) == 0u && (uint32_t)ra.mode == MODE_COLOR) {
-            const unsigned long long idle_mask = __ballot(phase == MESH_IDLE);
-            if (idle_mask != 0ull) {
-                bool cand = false;
-                uint32_t g_child = 0u, g_node = 0u;
-                int32_t g_level = 0, g_depth = 0;
-                f3 g_point = mk3(0.0f, 0.0f, 0.0f), g_dir = mk3(0.0f, 0.0f, 0.0f);
-                if (phase != MESH_IDLE && ln.level >= 1) {
-                    const bool waiting = phase == MESH_WAIT;
-                    // frames to look at: the fork frame if there is one, else all of them from the shallowest
-                    int32_t j0 = fork.level >= 0 ? fork.level : 0, j1 = fork.level >= 0 ? fork.level : ln.level - 1;
-                    for (int32_t j = j0; j <= j1 && !cand; j++) {
-                        const Frame f = frames.load(j);
-                        const int32_t child_depth = (int32_t)(f.meta >> 24);
-                        if (child_depth < kForkMinDepth) break;      // deeper frames have less depth left still
-                        const float metal = sc.materials[2u * (f.meta & 0x00FFFFFFu)].w;
-                        // node id of frame j and the child of it that is running (a waiting lane holds the frame's id)
-                        const uint32_t node_j = waiting ? ln.key.node : ln.key.node >> (2 * (ln.level - j));
-                        const uint32_t running = waiting ? (fork.bits >> 4) : ((ln.key.node >> (2 * (ln.level - 1 - j))) & 3u) - 1u;
-                        for (uint32_t c = 2u; c >= 1u && !cand; c--) {
-                            const bool exists = c == 1u ? (metal != 0.0f) : (metal != 1.0f);
-                            const bool given = j == fork.level && ((fork.bits >> c) & 1u) != 0u;
-                            if (c > running && exists && !given) {
-                                cand = true; g_child = c; g_node = node_j; g_level = j; g_depth = child_depth; g_point = f.point; g_dir = f.refl;
-                            }
-                        }
-                    }
-                }
-                const unsigned long long cand_mask = __ballot(cand);
-                const uint32_t n_cand = (uint32_t)__popcll(cand_mask), n_idle = (uint32_t)__popcll(idle_mask);
-                const uint32_t n_pairs = n_cand < n_idle ? n_cand : n_idle;
-                if (n_pairs != 0u) {
-                    const uint32_t rank_c = lanes_below(cand_mask), rank_i = lanes_below(idle_mask);
-                    const bool gives = cand && rank_c < n_pairs, takes = phase == MESH_IDLE && rank_i < n_pairs;
-                    if (gives) my_pair[rank_c] = lane;
-                    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-                    __builtin_amdgcn_wave_barrier();
-                    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-                    const int src = takes ? (int)my_pair[rank_i] : (int)lane;
-                    const uint32_t s_pixel = (uint32_t)__shfl((int)ln.key.pixel, src, 64), s_sample = (uint32_t)__shfl((int)ln.key.sample, src, 64);
-                    const uint32_t s_node = (uint32_t)__shfl((int)g_node, src, 64), s_child = (uint32_t)__shfl((int)g_child, src, 64);
-                    const int32_t s_depth = __shfl(g_depth, src, 64);
-                    const f3 s_point = mk3(__shfl(g_point.x, src, 64), __shfl(g_point.y, src, 64), __shfl(g_point.z, src, 64));
-                    const f3 s_dir = mk3(__shfl(g_dir.x, src, 64), __shfl(g_dir.y, src, 64), __shfl(g_dir.z, src, 64));
-                    if constexpr (COUNT) { if (lane == 0u) prof.cyc[15] += n_pairs; }   // diagnostics: subtrees handed over
-                    if (gives) {
-                        fork.level = g_level;
-                        fork.bits |= 1u << g_child;
-                        __hip_atomic_store(&my_mail[(size_t)(g_child - 1u) * 64 + lane].w, 0.0f, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                    }
-                    if (takes) {
-                        ln.key.seed = ra.seed; ln.key.pixel = s_pixel; ln.key.sample = s_sample;
-                        ln.key.node = s_node * 4u + s_child + 1u;
-                        ln.qo = s_point; ln.qd = s_dir; ln.qtmin = 0.01f;
-                        ln.depth = s_depth; ln.level = 0;
-                        fork.level = -1; fork.bits = 0u;
-                        deliver = src | (int32_t)(s_child << 8);
-                        tr.d = s_dir; tr.cur = TRAV_NEW; phase = MESH_CLOSEST;
-                    }
-                }
+            uint32_t handed = 0u;
+            if (share_subtrees(ln, phase, frames, fork, deliver, my_mail, my_pair, sc, ra, lane, handed)) {
+                tr.d = ln.qd; tr.cur = TRAV_NEW; phase = MESH_CLOSEST;
             }
+            if constexpr (COUNT) { if (lane == 0u) prof.cyc[15] += handed; }   // a count, not cycles
         }
         const bool walking = (phase == MESH_CLOSEST || phase == MESH_SHADOW) && tr.cur != TRAV_NONE;
         const int n_walk = __popcll(__ballot(walking));
@@ -558,9 +579,9 @@ hipError_t launch_trace(const SceneView& sc, const RenderArgs& ra, bool exact, b
     static const int walk_vote = std::getenv("SRT_WALK_VOTE") ? std::atoi(std::getenv("SRT_WALK_VOTE")) : kWalkVote;
     static const int walk_rounds = std::getenv("SRT_WALK_ROUNDS") ? std::atoi(std::getenv("SRT_WALK_ROUNDS")) : kWalkRounds;
     static const int walk_steps = std::getenv("SRT_WALK_STEPS") ? std::atoi(std::getenv("SRT_WALK_STEPS")) : kWalkSteps;
+    static const bool allow_fork = !std::getenv("SRT_NO_SUBTREE_SHARING");
+    float4* mailboxes = allow_fork ? reinterpret_cast<float4*>(d_mail) : nullptr;
     if (!stackless) {
-        static const bool allow_fork = !std::getenv("SRT_NO_SUBTREE_SHARING");
-        float4* mailboxes = allow_fork ? reinterpret_cast<float4*>(d_mail) : nullptr;
 #define SRT_LAUNCH_MESH(E, C) hipLaunchKernelGGL((mesh_trace_kernel<E, C>), grid, block, 0, stream, sc, ra, s, d_stats, d_work_counter, mailboxes, walk_vote, walk_rounds, walk_steps, chunk)
         if (exact) { if (counted) SRT_LAUNCH_MESH(true, true); else SRT_LAUNCH_MESH(true, false); }
         else { if (counted) SRT_LAUNCH_MESH(false, true); else SRT_LAUNCH_MESH(false, false); }

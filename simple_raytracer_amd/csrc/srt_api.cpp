@@ -7,7 +7,9 @@
 #include <chrono>
 #include <cstdlib>
 #include <cstring>
+#include <cstdio>
 #include <string>
+#include <vector>
 
 #include "../../include/srt.h"
 #include "srt_launch.h"
@@ -101,6 +103,13 @@ int collect_stats(srt_ctx* c)
     SRT_HIP(c, hipMemcpy(s, c->d_stats, sizeof(s), hipMemcpyDeviceToHost));
     SRT_HIP(c, hipMemsetAsync(c->d_stats, 0, sizeof(s), c->stream));
     SRT_HIP(c, hipStreamSynchronize(c->stream));
+#ifdef SRT_TIMELINE
+    if (const char* path = std::getenv("SRT_TIMELINE_FILE")) {
+        std::vector<unsigned long long> tl(3072 * 4);
+        hipMemcpy(tl.data(), reinterpret_cast<char*>(c->d_mail) + srt::trace_timeline_offset(), tl.size() * 8, hipMemcpyDeviceToHost);
+        if (FILE* f = std::fopen(path, "wb")) { std::fwrite(tl.data(), 8, tl.size(), f); std::fclose(f); }
+    }
+#endif
     float ms = 0.0f;
     SRT_HIP(c, hipEventElapsedTime(&ms, c->ev_begin, c->ev_end));
     c->stats.rays_path = s[0]; c->stats.rays_shadow = s[1]; c->stats.hit_nodes = s[2];

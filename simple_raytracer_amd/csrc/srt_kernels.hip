@@ -18,6 +18,7 @@
 // scenes and private memory otherwise.
 #include <hip/hip_runtime.h>
 
+#include <cstdio>
 #include <cstdlib>
 #include <type_traits>
 
@@ -40,7 +41,7 @@ constexpr int kBlock = 256;
 constexpr int kWaves = kBlock / 64;
 constexpr uint32_t kChunk = 256;       // items drawn from the global counter at a time
 constexpr int kTraceVote = 24;         // run the TRACE section while at least this many lanes want it
-constexpr int kMaxBlocks = 256 * 8;    // persistent grid: never more blocks than 8 per CU
+constexpr int kMaxBlocks = 256 * 5;    // persistent grid: never more blocks than 5 per CU (the mailboxes are sized for it)
 
 __device__ __forceinline__ unsigned long long wave_sum(unsigned long long v)
 {
@@ -67,35 +68,38 @@ struct ClockProf {
 
 // Sharing one ray tree between lanes.  Once the global counter is exhausted, a wavefront whose lanes are partly idle
 // lets busy lanes hand subtrees to the idle ones: a lane gives away child 1 or 2 (the metal / reflect child, whose ray
-// is stored in the frame) of its shallowest pending node, one node at a time.  The helper lane traces the subtree as a
-// work item of its own -- same pixel, sample and node id, hence the same random numbers and the same colour -- and
-// leaves the colour in the giver's mailbox (global memory, two slots per lane); the giver consumes it where it would
+// is stored in the frame) of its shallowest pending node that still has one, one subtree per round, so after a few
+// rounds it keeps only the first-child spine of its tree.  The helper lane traces the subtree as a work item of its
+// own -- same pixel, sample and node id, hence the same random numbers and the same colour -- and leaves the colour in
+// the giver's mailbox (global memory, one slot per lane, frame level and child); the giver consumes it where it would
 // have started that child (lane_return -> LANE_WAIT -> resumed as RETURN).  Helpers give away parts of their subtrees
-// in turn, so one deep tree (3,280 nodes at depth 8 with three children per node) spreads over the wavefront instead
-// of keeping one lane busy long after everything else has finished.  Results and ray counts do not change.
+// in turn, so one deep tree (255 nodes at depth 8 with two children per node, 3,280 with three) spreads over the
+// wavefront instead of keeping one lane busy long after everything else has finished: the time of a tree is then
+// set by its depth, not its node count.  Results and ray counts do not change.
+constexpr int kForkLevels = 8;         // frames at levels below this can give children away
 struct TreeFork {
-    int32_t level;     // the frame whose children are with other lanes (-1: none)
-    uint32_t bits;     // bit 1 / 2: child 1 / 2 of that frame is with another lane; bits 4-5: the child waited for
-    __device__ __forceinline__ bool donated(int32_t lvl, uint32_t child) const { return lvl == level && ((bits >> child) & 1u) != 0u; }
-    __device__ __forceinline__ void wait_for(uint32_t child) { bits = (bits & 0xFu) | (child << 4); }
+    uint32_t given;    // bit 2*level + child - 1: that child of the frame at `level` is with another lane
+    uint32_t wait;     // LANE_WAIT: the child (of the frame at ln.level - 1) whose colour the lane waits for
+    __device__ __forceinline__ bool donated(int32_t lvl, uint32_t child) const { return lvl < kForkLevels && ((given >> (2 * lvl + (int32_t)child - 1)) & 1u) != 0u; }
+    __device__ __forceinline__ void wait_for(uint32_t child) { wait = child; }
 };
-constexpr int kForkEvery = 4;          // look for subtrees to hand over on every kForkEvery-th trip of the main loop
+constexpr int kForkEvery = 4;          // mesh kernel: look for subtrees to hand over on every kForkEvery-th trip of the main loop
 constexpr int kForkMinDepth = 2;       // only subtrees that can still grow (remaining depth >= this)
-constexpr size_t kMailPerWave = 128;   // float4 entries: [child - 1][lane]
+constexpr size_t kMailPerWave = (size_t)kForkLevels * 2 * 64;   // float4 entries: [2*level + child - 1][lane]
 
 // A lane in LANE_WAIT: has the colour of the child it waits for arrived?  Then it continues in LANE_RETURN as if that
 // child had just returned.
 __device__ __forceinline__ void poll_mailbox(Lane& ln, int& phase, TreeFork& fork, float4* my_mail, uint32_t lane)
 {
     if (phase != LANE_WAIT) return;
-    const uint32_t c = fork.bits >> 4;
-    float4* slot = &my_mail[(size_t)(c - 1u) * 64 + lane];
+    const uint32_t c = fork.wait, bit = 2u * (uint32_t)(ln.level - 1) + c - 1u;
+    float4* slot = &my_mail[(size_t)bit * 64 + lane];
     if (__hip_atomic_load(&slot->w, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) == 1.0f) {
         ln.former = mk3(__hip_atomic_load(&slot->x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT),
                         __hip_atomic_load(&slot->y, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT),
                         __hip_atomic_load(&slot->z, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
         ln.key.node = ln.key.node * 4u + c + 1u;
-        fork.bits &= 0xFu & ~(1u << c);
+        fork.given &= ~(1u << bit);
         phase = LANE_RETURN;
     }
 }
@@ -105,7 +109,7 @@ __device__ __forceinline__ void poll_mailbox(Lane& ln, int& phase, TreeFork& for
 __device__ __forceinline__ void deliver_colour(const Lane& ln, f3 ret, int32_t& deliver, float4* my_mail, f3* __restrict__ samples)
 {
     if (deliver >= 0) {
-        float4* slot = &my_mail[(size_t)((deliver >> 8) - 1) * 64 + (size_t)(deliver & 63)];
+        float4* slot = &my_mail[(size_t)(deliver >> 8) * 64 + (size_t)(deliver & 63)];
         __hip_atomic_store(&slot->x, ret.x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         __hip_atomic_store(&slot->y, ret.y, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         __hip_atomic_store(&slot->z, ret.z, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -126,26 +130,26 @@ __device__ __forceinline__ bool share_subtrees(Lane& ln, int phase, const FRAMES
     const unsigned long long idle_mask = __ballot(phase == LANE_IDLE);
     if (idle_mask == 0ull) return false;
     bool cand = false;
-    uint32_t g_child = 0u, g_node = 0u;
-    int32_t g_level = 0, g_depth = 0;
+    uint32_t g_bit = 0u, g_node = 0u;
+    int32_t g_depth = 0;
     f3 g_point = mk3(0.0f, 0.0f, 0.0f), g_dir = mk3(0.0f, 0.0f, 0.0f);
     if (phase != LANE_IDLE && ln.level >= 1) {
-        const bool waiting = phase == LANE_WAIT;
-        // frames to look at: the fork frame if there is one, else all of them from the shallowest
-        int32_t j0 = fork.level >= 0 ? fork.level : 0, j1 = fork.level >= 0 ? fork.level : ln.level - 1;
-        for (int32_t j = j0; j <= j1 && !cand; j++) {
+        // A waiting lane holds the id of its deepest frame's node, any other lane the id of a node one level below.
+        const int32_t below = phase == LANE_WAIT ? ln.level - 1 : ln.level;
+        const int32_t j1 = ln.level - 1 < kForkLevels - 1 ? ln.level - 1 : kForkLevels - 1;
+        for (int32_t j = 0; j <= j1 && !cand; j++) {
             const Frame f = frames.load(j);
             const int32_t child_depth = (int32_t)(f.meta >> 24);
             if (child_depth < kForkMinDepth) break;      // deeper frames have less depth left still
             const float metal = sc.materials[2u * (f.meta & 0x00FFFFFFu)].w;
-            // node id of frame j and the child of it that is running (a waiting lane holds the frame's id)
-            const uint32_t node_j = waiting ? ln.key.node : ln.key.node >> (2 * (ln.level - j));
-            const uint32_t running = waiting ? (fork.bits >> 4) : ((ln.key.node >> (2 * (ln.level - 1 - j))) & 3u) - 1u;
+            // node id of frame j and the child of it that is running (or, at a waiting lane's deepest frame, waited for)
+            const uint32_t node_j = ln.key.node >> (2 * (below - j));
+            const uint32_t running = j == below ? fork.wait : ((ln.key.node >> (2 * (below - 1 - j))) & 3u) - 1u;
             for (uint32_t c = 2u; c >= 1u && !cand; c--) {
                 const bool exists = c == 1u ? (metal != 0.0f) : (metal != 1.0f);
-                const bool given = j == fork.level && ((fork.bits >> c) & 1u) != 0u;
-                if (c > running && exists && !given) {
-                    cand = true; g_child = c; g_node = node_j; g_level = j; g_depth = child_depth; g_point = f.point; g_dir = f.refl;
+                const uint32_t bit = 2u * (uint32_t)j + c - 1u;
+                if (c > running && exists && ((fork.given >> bit) & 1u) == 0u) {
+                    cand = true; g_bit = bit; g_node = node_j * 4u + c + 1u; g_depth = child_depth; g_point = f.point; g_dir = f.refl;
                 }
             }
         }
@@ -163,22 +167,21 @@ __device__ __forceinline__ bool share_subtrees(Lane& ln, int phase, const FRAMES
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
     const int src = takes ? (int)my_pair[rank_i] : (int)lane;
     const uint32_t s_pixel = (uint32_t)__shfl((int)ln.key.pixel, src, 64), s_sample = (uint32_t)__shfl((int)ln.key.sample, src, 64);
-    const uint32_t s_node = (uint32_t)__shfl((int)g_node, src, 64), s_child = (uint32_t)__shfl((int)g_child, src, 64);
+    const uint32_t s_node = (uint32_t)__shfl((int)g_node, src, 64), s_bit = (uint32_t)__shfl((int)g_bit, src, 64);
     const int32_t s_depth = __shfl(g_depth, src, 64);
     const f3 s_point = mk3(__shfl(g_point.x, src, 64), __shfl(g_point.y, src, 64), __shfl(g_point.z, src, 64));
     const f3 s_dir = mk3(__shfl(g_dir.x, src, 64), __shfl(g_dir.y, src, 64), __shfl(g_dir.z, src, 64));
     if (gives) {
-        fork.level = g_level;
-        fork.bits |= 1u << g_child;
-        __hip_atomic_store(&my_mail[(size_t)(g_child - 1u) * 64 + lane].w, 0.0f, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        fork.given |= 1u << g_bit;
+        __hip_atomic_store(&my_mail[(size_t)g_bit * 64 + lane].w, 0.0f, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
     if (takes) {
         ln.key.seed = ra.seed; ln.key.pixel = s_pixel; ln.key.sample = s_sample;
-        ln.key.node = s_node * 4u + s_child + 1u;
+        ln.key.node = s_node;
         ln.qo = s_point; ln.qd = s_dir; ln.qtmin = 0.01f;
         ln.depth = s_depth; ln.level = 0;
-        fork.level = -1; fork.bits = 0u;
-        deliver = src | (int32_t)(s_child << 8);
+        fork.given = 0u; fork.wait = 0u;
+        deliver = src | (int32_t)(s_bit << 8);
     }
     return takes;
 }
@@ -200,7 +203,7 @@ __device__ __forceinline__ void copy_words(q4* dst, const q4* src, uint32_t n)
 template <bool EXACT, bool COUNT, bool SMALL>
 __global__ void __launch_bounds__(kBlock, SMALL ? SRT_WAVES_PER_SIMD : SRT_WAVES_PER_SIMD_BIG) trace_kernel(SceneView gsc, RenderArgs ra, f3* __restrict__ samples,
                                                        unsigned long long* __restrict__ stats, uint32_t* __restrict__ work_counter,
-                                                       int trace_vote, uint32_t chunk)
+                                                       float4* __restrict__ mail /* -DSRT_TIMELINE builds only */, int trace_vote, uint32_t chunk)
 {
     __shared__ float lds_frames[SMALL ? kWaves * kLdsFrameLevels * 14 * 64 : 1];
     __shared__ float unit[UNIT_TABLE];   // (d - 100) / 100 for the RNG's base-200 digits
@@ -220,6 +223,10 @@ __global__ void __launch_bounds__(kBlock, SMALL ? SRT_WAVES_PER_SIMD : SRT_WAVES
     }
     __syncthreads();
 
+#ifdef SRT_TIMELINE
+    const unsigned long long tl_start = wall_clock64();
+    unsigned long long tl_dry = 0ull, tl_trips = 0ull;
+#endif
     Lane ln;
     Frame frame_mem[FRAME_SLOTS];
     typename std::conditional<SMALL, HybridFrames<kLdsFrameLevels>, PrivateFrames>::type frames;
@@ -237,9 +244,13 @@ __global__ void __launch_bounds__(kBlock, SMALL ? SRT_WAVES_PER_SIMD : SRT_WAVES
 #define SRT_MARK(i) prof.mark(i)
     uint32_t next = 0u, end = 0u;  // wave-uniform: the wavefront's private range of items
     bool dry = false;              // wave-uniform: the global counter is exhausted
+    unsigned long long t_dry = 0ull;   // counting builds: wall clock (100 MHz) when this wavefront found the counter exhausted
 
     for (;;) {
         if constexpr (COUNT) prof.start();
+#ifdef SRT_TIMELINE
+        if (dry) tl_trips++; else tl_trips += 1ull << 32;
+#endif
         const int n_trace = __popcll(__ballot(phase == LANE_TRACE || phase == LANE_RETURN || (phase == LANE_IDLE && !dry)));
         const int n_light = __popcll(__ballot(phase == LANE_LIGHT));
         if (n_trace + n_light == 0) break;
@@ -260,7 +271,14 @@ __global__ void __launch_bounds__(kBlock, SMALL ? SRT_WAVES_PER_SIMD : SRT_WAVES
                     uint32_t base = 0u;
                     if (lane == 0u) base = atomicAdd(work_counter, chunk);
                     base = __builtin_amdgcn_readfirstlane(base);
-                    if (base >= ra.n_items) { dry = true; break; }
+                    if (base >= ra.n_items) {
+                        dry = true;
+                        if constexpr (COUNT) t_dry = wall_clock64();
+#ifdef SRT_TIMELINE
+                        tl_dry = wall_clock64();
+#endif
+                        break;
+                    }
                     next = base;
                     end = base + chunk < ra.n_items ? base + chunk : ra.n_items;
                 }
@@ -307,6 +325,13 @@ __global__ void __launch_bounds__(kBlock, SMALL ? SRT_WAVES_PER_SIMD : SRT_WAVES
         }
     }
 
+#ifdef SRT_TIMELINE
+    if (lane == 0u) {
+        unsigned long long* rec = reinterpret_cast<unsigned long long*>(mail + (size_t)1000 * kWaves * kMailPerWave) + ((size_t)blockIdx.x * kWaves + wave) * 4;
+        rec[0] = tl_start; rec[1] = tl_dry; rec[2] = wall_clock64(); rec[3] = tl_trips;
+    }
+#endif
+    const unsigned long long t_exit = COUNT ? wall_clock64() : 0ull;
     unsigned long long v0 = wave_sum(ln.rays_path), v1 = wave_sum(ln.rays_shadow), v2 = wave_sum(ln.hit_nodes);
     if (lane == 0u) {
         atomicAdd(&stats[0], v0);
@@ -322,6 +347,12 @@ __global__ void __launch_bounds__(kBlock, SMALL ? SRT_WAVES_PER_SIMD : SRT_WAVES
             atomicAdd(&stats[6], c3);
             for (int i = 0; i < 4; i++) atomicAdd(&stats[7 + i], (unsigned long long)sect[i]);
             for (int i = 0; i < PROF_SLOTS; i++) atomicAdd(&stats[16 + i], prof.cyc[i]);
+            // the tail of the launch: how long wavefronts kept running after the counter ran out (100 MHz ticks)
+            const unsigned long long tail = t_exit - t_dry;
+            atomicMax(&stats[16 + 11], tail);
+            atomicAdd(&stats[16 + 12], tail);
+            if (tail > 25000ull) atomicAdd(&stats[16 + 13], 1ull);
+            if (tail > 100000ull) atomicAdd(&stats[16 + 14], 1ull);
         }
     }
 }
@@ -374,7 +405,7 @@ __global__ void __launch_bounds__(kBlock, SRT_WAVES_PER_SIMD_MESH) mesh_trace_ke
     ln.level = 0; ln.key.node = 0u;
     int phase = MESH_IDLE;
     TreeFork fork;
-    fork.level = -1; fork.bits = 0u;
+    fork.given = 0u; fork.wait = 0u;
     int32_t deliver = -1;      // >= 0: this lane traces a subtree for lane (deliver & 63), child (deliver >> 8) of its fork frame
     float4* my_mail = mail ? mail + ((size_t)blockIdx.x * kWaves + wave) * kMailPerWave : nullptr;
     uint32_t* my_pair = &lds_pair[wave * 64];
@@ -387,7 +418,6 @@ __global__ void __launch_bounds__(kBlock, SRT_WAVES_PER_SIMD_MESH) mesh_trace_ke
 
     // the lane's next state after a per-lane function returned LANE_*; `ret` is the sample's colour for LANE_IDLE
     auto enter = [&](int lane_phase, f3 ret) {
-        if (fork.level >= 0 && ln.level <= fork.level) { fork.level = -1; fork.bits = 0u; }   // the fork frame is complete
         if (lane_phase == LANE_IDLE) { deliver_colour(ln, ret, deliver, my_mail, samples); phase = MESH_IDLE; }
         else if (lane_phase == LANE_WAIT) phase = MESH_WAIT;
         else if (lane_phase == LANE_RETURN) phase = MESH_RETURN;
@@ -551,6 +581,20 @@ __global__ void __launch_bounds__(kBlock) assemble_kernel(RenderArgs ra, const u
     frame[i] = gathered[(size_t)r * stride + (size_t)j * (uint32_t)(ra.tile_w * ra.tile_h) + ly * (uint32_t)ra.tile_w + lx];
 }
 
+// Blocks of a persistent kernel that the device keeps resident at once.  More than that is useless: the surplus only
+// starts when the first blocks have run the counter dry, and each still pays its prologue and its statistics atomics.
+template <class K>
+static uint32_t resident_blocks(K kernel)
+{
+    int per_cu = 0, dev = 0;
+    hipDeviceProp_t prop;
+    if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess ||
+        hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kernel, kBlock, 0) != hipSuccess || per_cu <= 0)
+        return (uint32_t)kMaxBlocks;
+    uint32_t n = (uint32_t)per_cu * (uint32_t)prop.multiProcessorCount;
+    return n < (uint32_t)kMaxBlocks ? n : (uint32_t)kMaxBlocks;
+}
+
 hipError_t launch_trace(const SceneView& sc, const RenderArgs& ra, bool exact, bool counted, float* d_samples,
                         unsigned long long* d_stats, uint32_t* d_work_counter, float* d_mail, hipStream_t stream)
 {
@@ -561,7 +605,29 @@ hipError_t launch_trace(const SceneView& sc, const RenderArgs& ra, bool exact, b
     static const int vote = std::getenv("SRT_TRACE_VOTE") ? std::atoi(std::getenv("SRT_TRACE_VOTE")) : kTraceVote;
     static const uint32_t chunk_knob = std::getenv("SRT_CHUNK") ? (uint32_t)std::atoi(std::getenv("SRT_CHUNK")) : 0u;
     static const uint32_t max_blocks = std::getenv("SRT_MAX_BLOCKS") ? (uint32_t)std::atoi(std::getenv("SRT_MAX_BLOCKS")) : (uint32_t)kMaxBlocks;
+    static const bool allow_small = !std::getenv("SRT_NO_LDS_SCENE");
+    const bool stackless = sc.has_bvh == 0u || (exact && sc.n_tiny != 0u);
+    const bool small = allow_small && stackless && sc.n_prims <= kSmallPrims && sc.n_materials <= kSmallMaterials;
+    // one entry per kernel instantiation: [mesh][exact][counted][small]
+    static uint32_t resident[2][2][2][2] = {};
+    uint32_t& fit = resident[stackless ? 0 : 1][exact ? 1 : 0][counted ? 1 : 0][small ? 1 : 0];
+    if (fit == 0u) {
+#define SRT_FIT(...) fit = resident_blocks(__VA_ARGS__)
+        if (!stackless) {
+            if (exact) { if (counted) SRT_FIT(mesh_trace_kernel<true, true>); else SRT_FIT(mesh_trace_kernel<true, false>); }
+            else { if (counted) SRT_FIT(mesh_trace_kernel<false, true>); else SRT_FIT(mesh_trace_kernel<false, false>); }
+        } else if (exact) {
+            if (counted) { if (small) SRT_FIT(trace_kernel<true, true, true>); else SRT_FIT(trace_kernel<true, true, false>); }
+            else { if (small) SRT_FIT(trace_kernel<true, false, true>); else SRT_FIT(trace_kernel<true, false, false>); }
+        } else {
+            if (counted) { if (small) SRT_FIT(trace_kernel<false, true, true>); else SRT_FIT(trace_kernel<false, true, false>); }
+            else { if (small) SRT_FIT(trace_kernel<false, false, true>); else SRT_FIT(trace_kernel<false, false, false>); }
+        }
+#undef SRT_FIT
+        if (std::getenv("SRT_DEBUG_LAUNCH")) std::fprintf(stderr, "srt: %u resident blocks\n", fit);
+    }
     uint32_t blocks = (ra.n_items + kBlock - 1) / kBlock;
+    if (blocks > fit) blocks = fit;
     if (blocks > max_blocks) blocks = max_blocks;
     dim3 grid(blocks), block(kBlock);
     // Items per draw from the global counter: kChunk for big passes; a short pass gets smaller ranges (down to one
@@ -572,9 +638,6 @@ hipError_t launch_trace(const SceneView& sc, const RenderArgs& ra, bool exact, b
         chunk = share >= kChunk ? kChunk : (share < 64u ? 64u : (share & ~63u));
     }
     f3* s = reinterpret_cast<f3*>(d_samples);
-    static const bool allow_small = !std::getenv("SRT_NO_LDS_SCENE");
-    const bool stackless = sc.has_bvh == 0u || (exact && sc.n_tiny != 0u);
-    const bool small = allow_small && stackless && sc.n_prims <= kSmallPrims && sc.n_materials <= kSmallMaterials;
     // Scenes whose tree is walked with a stack get the kernel that schedules traversal in quanta.
     static const int walk_vote = std::getenv("SRT_WALK_VOTE") ? std::atoi(std::getenv("SRT_WALK_VOTE")) : kWalkVote;
     static const int walk_rounds = std::getenv("SRT_WALK_ROUNDS") ? std::atoi(std::getenv("SRT_WALK_ROUNDS")) : kWalkRounds;
@@ -588,7 +651,7 @@ hipError_t launch_trace(const SceneView& sc, const RenderArgs& ra, bool exact, b
 #undef SRT_LAUNCH_MESH
         return hipGetLastError();
     }
-#define SRT_LAUNCH(E, C, S) hipLaunchKernelGGL((trace_kernel<E, C, S>), grid, block, 0, stream, sc, ra, s, d_stats, d_work_counter, vote, chunk)
+#define SRT_LAUNCH(E, C, S) hipLaunchKernelGGL((trace_kernel<E, C, S>), grid, block, 0, stream, sc, ra, s, d_stats, d_work_counter, mailboxes, vote, chunk)
     if (exact) {
         if (counted) { if (small) SRT_LAUNCH(true, true, true); else SRT_LAUNCH(true, true, false); }
         else { if (small) SRT_LAUNCH(true, false, true); else SRT_LAUNCH(true, false, false); }
@@ -600,6 +663,7 @@ hipError_t launch_trace(const SceneView& sc, const RenderArgs& ra, bool exact, b
     return hipGetLastError();
 }
 
+size_t trace_timeline_offset() { return (size_t)1000 * kWaves * kMailPerWave * sizeof(float4); }
 size_t trace_mail_bytes() { return (size_t)kMaxBlocks * kWaves * kMailPerWave * sizeof(float4); }
 
 hipError_t launch_resolve(const RenderArgs& ra, const float* d_samples, float* d_running, uint32_t* d_out, bool first_pass, bool last_pass,

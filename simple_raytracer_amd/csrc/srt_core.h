@@ -682,7 +682,24 @@ struct RenderArgs {
     // one pass of the trace kernel covers samples [sample_first, sample_first + sample_count) of every pixel
     uint32_t sample_first, sample_count;
     uint32_t n_items;               // n_work * sample_count work items (one per pixel and sample)
+    // The first `coherent` samples of the pass are enumerated block by block: 64 consecutive items are one 8x8 pixel
+    // block at one sample index (neighbouring rays take the same branches and share nodes and cache lines).  The
+    // remaining samples come one after the other, and inside a sample item i is position i % 64 of block
+    // (i / 64 + (i % 64) * scatter) mod (n_work / 64): 64 consecutive items come from 64 blocks spread over the
+    // picture, so every draw of items costs about the same and no wavefront ends the launch with a pile of deep trees.
+    uint32_t coherent, scatter;
 };
+
+// Item order of one pass (after sample_count is set): the last `scatter_samples` samples in scattered order.
+inline void set_item_order(RenderArgs& ra, uint32_t scatter_samples)
+{
+    ra.coherent = ra.sample_count;
+    ra.scatter = 0u;
+    if (scatter_samples != 0u && ra.n_work >= 128u) {
+        ra.coherent = ra.sample_count > scatter_samples ? ra.sample_count - scatter_samples : 0u;
+        ra.scatter = ((ra.n_work >> 6) / 64u) | 1u;
+    }
+}
 
 // A parent waiting for its children (one per pending level of the recursion).
 struct Frame {

@@ -40,6 +40,7 @@ namespace srt {
 constexpr int kBlock = 256;
 constexpr int kWaves = kBlock / 64;
 constexpr uint32_t kChunk = 256;       // items drawn from the global counter at a time
+constexpr uint32_t kScatterSamples = 2; // trace_kernel: samples at the end of a pass that are enumerated in scattered order
 constexpr int kTraceVote = 24;         // run the TRACE section while at least this many lanes want it
 constexpr int kMaxBlocks = 256 * 5;    // persistent grid: never more blocks than 5 per CU (the mailboxes are sized for it)
 
@@ -186,6 +187,101 @@ __device__ __forceinline__ bool share_subtrees(Lane& ln, int phase, const FRAMES
     return takes;
 }
 
+// trace_kernel's closing loop shares trees the same way but without memory in between: a helper that has its subtree's
+// colour keeps it (LANE_DELIVER) until the giver waits for exactly that child, and then it travels by readlane.  The
+// children that a lane can still give away are kept in a bit mask (`open`, bit 2*level + child - 1) instead of being
+// searched for in the frames.
+enum { LANE_DELIVER = 5 };
+
+// `open` of a lane that enters the closing loop in the middle of a tree
+template <class FRAMES>
+__device__ __forceinline__ uint32_t open_children(const Lane& ln, int phase, const FRAMES& frames, const SceneView& sc)
+{
+    uint32_t open = 0u;
+    if (phase == LANE_IDLE) return open;
+    for (int32_t j = 0; j < ln.level && j < kForkLevels; j++) {
+        const Frame f = frames.load(j);
+        if ((int32_t)(f.meta >> 24) < kForkMinDepth) break;      // deeper frames have less depth left still
+        const float metal = sc.materials[2u * (f.meta & 0x00FFFFFFu)].w;
+        const uint32_t running = ((ln.key.node >> (2 * (ln.level - 1 - j))) & 3u) - 1u;
+        if (metal != 0.0f && running < 1u) open |= 1u << (2 * j);
+        if (metal != 1.0f && running < 2u) open |= 2u << (2 * j);
+    }
+    return open;
+}
+
+// Helpers whose giver waits for their subtree hand the colour over.
+__device__ __forceinline__ void rendezvous(Lane& ln, int& phase, TreeFork& fork, int32_t& deliver, uint32_t lane)
+{
+    if (__ballot(phase == LANE_DELIVER) == 0ull) return;
+    const int g = phase == LANE_DELIVER ? (deliver & 63) : (int)lane;
+    const uint32_t my_wait = phase == LANE_WAIT ? 2u * (uint32_t)(ln.level - 1) + fork.wait - 1u : 0xFFFFFFFFu;
+    const uint32_t g_wait = (uint32_t)__shfl((int)my_wait, g, 64);
+    unsigned long long match = __ballot(phase == LANE_DELIVER && g_wait == (uint32_t)(deliver >> 8));
+    while (match != 0ull) {
+        const int h = (int)__builtin_ctzll(match);
+        match &= match - 1ull;
+        const uint32_t to = (uint32_t)__builtin_amdgcn_readlane(g, h);
+        const float x = bitsf((uint32_t)__builtin_amdgcn_readlane((int)fbits(ln.former.x), h));
+        const float y = bitsf((uint32_t)__builtin_amdgcn_readlane((int)fbits(ln.former.y), h));
+        const float z = bitsf((uint32_t)__builtin_amdgcn_readlane((int)fbits(ln.former.z), h));
+        if (lane == to) {
+            ln.former = mk3(x, y, z);
+            ln.key.node = ln.key.node * 4u + fork.wait + 1u;
+            fork.given &= ~(1u << my_wait);
+            phase = LANE_RETURN;
+        }
+        if (lane == (uint32_t)h) { phase = LANE_IDLE; deliver = -1; }
+    }
+}
+
+// Pairs lanes that can give a child away with idle lanes; returns true on the lanes that took one (see share_subtrees).
+template <class FRAMES>
+__device__ __forceinline__ bool share_open_children(Lane& ln, int phase, const FRAMES& frames, TreeFork& fork, uint32_t& open, int32_t& deliver,
+                                                    uint32_t* my_pair, const RenderArgs& ra, uint32_t lane)
+{
+    const unsigned long long idle_mask = __ballot(phase == LANE_IDLE);
+    const bool cand = phase != LANE_IDLE && phase != LANE_DELIVER && open != 0u;
+    const unsigned long long cand_mask = __ballot(cand);
+    const uint32_t n_cand = (uint32_t)__popcll(cand_mask), n_idle = (uint32_t)__popcll(idle_mask);
+    const uint32_t n_pairs = n_cand < n_idle ? n_cand : n_idle;
+    if (n_pairs == 0u) return false;
+    const uint32_t rank_c = lanes_below(cand_mask), rank_i = lanes_below(idle_mask);
+    const bool gives = cand && rank_c < n_pairs, takes = phase == LANE_IDLE && rank_i < n_pairs;
+    uint32_t g_bit = 0u, g_node = 0u;
+    int32_t g_depth = 0;
+    f3 g_point = mk3(0.0f, 0.0f, 0.0f), g_dir = mk3(0.0f, 0.0f, 0.0f);
+    if (gives) {
+        g_bit = (uint32_t)__builtin_ctz(open);                 // the shallowest frame: the largest subtree
+        const int32_t j = (int32_t)(g_bit >> 1);
+        const Frame f = frames.load(j);
+        g_point = f.point; g_dir = f.refl; g_depth = (int32_t)(f.meta >> 24);
+        const int32_t below = phase == LANE_WAIT ? ln.level - 1 : ln.level;   // a waiting lane holds its deepest frame's node id
+        g_node = (ln.key.node >> (2 * (below - j))) * 4u + (g_bit & 1u) + 2u;
+        open &= ~(1u << g_bit);
+        fork.given |= 1u << g_bit;
+        my_pair[rank_c] = lane;
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    const int src = takes ? (int)my_pair[rank_i] : (int)lane;
+    const uint32_t s_pixel = (uint32_t)__shfl((int)ln.key.pixel, src, 64), s_sample = (uint32_t)__shfl((int)ln.key.sample, src, 64);
+    const uint32_t s_node = (uint32_t)__shfl((int)g_node, src, 64), s_bit = (uint32_t)__shfl((int)g_bit, src, 64);
+    const int32_t s_depth = __shfl(g_depth, src, 64);
+    const f3 s_point = mk3(__shfl(g_point.x, src, 64), __shfl(g_point.y, src, 64), __shfl(g_point.z, src, 64));
+    const f3 s_dir = mk3(__shfl(g_dir.x, src, 64), __shfl(g_dir.y, src, 64), __shfl(g_dir.z, src, 64));
+    if (takes) {
+        ln.key.seed = ra.seed; ln.key.pixel = s_pixel; ln.key.sample = s_sample;
+        ln.key.node = s_node;
+        ln.qo = s_point; ln.qd = s_dir; ln.qtmin = 0.01f;
+        ln.depth = s_depth; ln.level = 0;
+        fork.given = 0u; fork.wait = 0u; open = 0u;
+        deliver = src | (int32_t)(s_bit << 8);
+    }
+    return takes;
+}
+
 // SMALL kernels serve scenes that need no traversal stack (a reference tree of a few nodes, walked with the
 // wave-uniform loop, or a handful of surfaces scanned linearly) and whose primitive and material tables fit the
 // limits below.  Their LDS holds those two tables (they are indexed per lane) and the first kLdsFrameLevels
@@ -203,9 +299,10 @@ __device__ __forceinline__ void copy_words(q4* dst, const q4* src, uint32_t n)
 template <bool EXACT, bool COUNT, bool SMALL>
 __global__ void __launch_bounds__(kBlock, SMALL ? SRT_WAVES_PER_SIMD : SRT_WAVES_PER_SIMD_BIG) trace_kernel(SceneView gsc, RenderArgs ra, f3* __restrict__ samples,
                                                        unsigned long long* __restrict__ stats, uint32_t* __restrict__ work_counter,
-                                                       float4* __restrict__ mail /* -DSRT_TIMELINE builds only */, int trace_vote, uint32_t chunk)
+                                                       float4* __restrict__ mail /* -DSRT_TIMELINE builds only */, int trace_vote, uint32_t chunk, int share, uint32_t last_stretch)
 {
     __shared__ float lds_frames[SMALL ? kWaves * kLdsFrameLevels * 14 * 64 : 1];
+    __shared__ uint32_t lds_pair[kWaves * 64];   // handing over subtrees: giver lane by rank
     __shared__ float unit[UNIT_TABLE];   // (d - 100) / 100 for the RNG's base-200 digits
     __shared__ q4 small_tables[SMALL ? kSmallWords : 1];
     const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
@@ -244,6 +341,7 @@ __global__ void __launch_bounds__(kBlock, SMALL ? SRT_WAVES_PER_SIMD : SRT_WAVES
 #define SRT_MARK(i) prof.mark(i)
     uint32_t next = 0u, end = 0u;  // wave-uniform: the wavefront's private range of items
     bool dry = false;              // wave-uniform: the global counter is exhausted
+    uint32_t draw = chunk;         // wave-uniform: items per draw from the global counter
     unsigned long long t_dry = 0ull;   // counting builds: wall clock (100 MHz) when this wavefront found the counter exhausted
 
     for (;;) {
@@ -251,6 +349,7 @@ __global__ void __launch_bounds__(kBlock, SMALL ? SRT_WAVES_PER_SIMD : SRT_WAVES
 #ifdef SRT_TIMELINE
         if (dry) tl_trips++; else tl_trips += 1ull << 32;
 #endif
+        if (dry && share != 0) break;   // no new items: the trees that are still being walked finish in the loop below
         const int n_trace = __popcll(__ballot(phase == LANE_TRACE || phase == LANE_RETURN || (phase == LANE_IDLE && !dry)));
         const int n_light = __popcll(__ballot(phase == LANE_LIGHT));
         if (n_trace + n_light == 0) break;
@@ -269,7 +368,7 @@ __global__ void __launch_bounds__(kBlock, SMALL ? SRT_WAVES_PER_SIMD : SRT_WAVES
                 if (next >= end) {
                     if (dry) break;
                     uint32_t base = 0u;
-                    if (lane == 0u) base = atomicAdd(work_counter, chunk);
+                    if (lane == 0u) base = atomicAdd(work_counter, draw);
                     base = __builtin_amdgcn_readfirstlane(base);
                     if (base >= ra.n_items) {
                         dry = true;
@@ -280,7 +379,10 @@ __global__ void __launch_bounds__(kBlock, SMALL ? SRT_WAVES_PER_SIMD : SRT_WAVES
                         break;
                     }
                     next = base;
-                    end = base + chunk < ra.n_items ? base + chunk : ra.n_items;
+                    end = base + draw < ra.n_items ? base + draw : ra.n_items;
+                    // the last stretch of the block-ordered items is drawn in small pieces, so that no wavefront is left
+                    // with a pile of deep trees of its own when the others move on to the scattered items
+                    draw = ra.n_work * ra.coherent - end < last_stretch ? 64u : chunk;
                 }
                 uint32_t avail = end - next, want = (uint32_t)__popcll(idle);
                 uint32_t rank = lanes_below(idle);
@@ -322,6 +424,76 @@ __global__ void __launch_bounds__(kBlock, SMALL ? SRT_WAVES_PER_SIMD : SRT_WAVES
                 if (phase == LANE_IDLE) samples[ln.slot] = ret;
             }
             SRT_MARK(PROF_CHILD_START);
+        }
+    }
+
+    // ---- the end of the launch: no new items.  Lanes without work take subtrees from the lanes that still have a
+    // tree, so that the time of the last deep trees is set by their depth and not by their node count.
+    if (dry && share != 0) {
+        TreeFork fork;
+        fork.given = 0u; fork.wait = 0u;
+        int32_t deliver = -1;      // >= 0: this lane walks a subtree for lane (deliver & 63); deliver >> 8 is the giver's bit for it
+        uint32_t open = open_children(ln, phase, frames, sc);
+        uint32_t* my_pair = &lds_pair[wave * 64];
+        // a tree ended: its colour is a sample, or waits for the giver
+        auto finish = [&](f3 ret) {
+            if (deliver >= 0) { ln.former = ret; phase = LANE_DELIVER; }
+            else { samples[ln.slot] = ret; phase = LANE_IDLE; }
+        };
+        // a frame was pushed for the node at ln.level - 1 and its child 0 started: which other children can be given away
+        auto pushed = [&]() {
+            const int32_t j = ln.level - 1;
+            if (j >= kForkLevels || ln.depth < kForkMinDepth) return;
+            const float metal = sc.materials[2u * ln.mat].w;
+            if (metal != 0.0f) open |= 1u << (2 * j);
+            if (metal != 1.0f) open |= 2u << (2 * j);
+        };
+        for (;;) {
+#ifdef SRT_TIMELINE
+            tl_trips++;
+#endif
+            rendezvous(ln, phase, fork, deliver, lane);
+            if (share_open_children(ln, phase, frames, fork, open, deliver, my_pair, ra, lane)) phase = LANE_TRACE;
+            const unsigned long long m_trace = __ballot(phase == LANE_TRACE || phase == LANE_RETURN), m_light = __ballot(phase == LANE_LIGHT);
+            if ((m_trace | m_light) == 0ull) {
+                if (__ballot(phase == LANE_WAIT) == 0ull) break;
+                continue;   // givers and helpers that meet at the top of the loop
+            }
+            if (m_trace != 0ull) {
+                if (phase == LANE_RETURN) {
+                    f3 ret;
+                    const int p = lane_return(ln, ret, sc, ra, frames, fork);
+                    // frames above the current level are gone; a child that starts can no longer be given away
+                    open &= ln.level < 16 ? (1u << (2 * ln.level)) - 1u : 0xFFFFFFFFu;
+                    if (p == LANE_TRACE) { const uint32_t c = (ln.key.node & 3u) - 1u; if (ln.level - 1 < kForkLevels) open &= ~(1u << (2 * (ln.level - 1) + (int32_t)c - 1)); }
+                    if (p == LANE_IDLE) finish(ret); else phase = p;
+                }
+                if (COUNT) { sect[0]++; sect[1] += (uint32_t)__popcll(__ballot(phase == LANE_TRACE)); }
+                if (phase == LANE_TRACE) {
+                    Hit h = closest_hit<EXACT, COUNT>(sc, ln.qo, ln.qd, ln.qtmin, cnt);
+                    f3 ret;
+                    const int p = lane_on_closest(ln, h, ret, sc, ra, frames, unit);
+                    if (p == LANE_TRACE) pushed();      // a scene without lights: the node was shaded at once
+                    if (p == LANE_IDLE) finish(ret); else phase = p;
+                }
+            }
+            if (__ballot(phase == LANE_LIGHT) != 0ull) {
+                if (COUNT) { sect[2]++; sect[3] += (uint32_t)__popcll(__ballot(phase == LANE_LIGHT)); }
+                if (phase == LANE_LIGHT) {
+                    uint32_t aux[4];
+                    rng_call(ln.key, CALL_AUX, aux);
+                    for (uint32_t li = 0; li < sc.n_lights; li++) {
+                        f3 o, d;
+                        lane_shadow_query(ln, sc, li, aux, unit, o, d);
+                        Hit h = closest_hit<EXACT, COUNT>(sc, o, d, 0.001f, cnt);
+                        lane_on_shadow(ln, h, o, d, sc, li);
+                    }
+                    f3 ret;
+                    const int p = lane_shade(ln, ln.former, ret, sc, ra, frames, aux, unit);
+                    if (p == LANE_TRACE) pushed();
+                    if (p == LANE_IDLE) finish(ret); else phase = p;
+                }
+            }
         }
     }
 
@@ -595,10 +767,12 @@ static uint32_t resident_blocks(K kernel)
     return n < (uint32_t)kMaxBlocks ? n : (uint32_t)kMaxBlocks;
 }
 
-hipError_t launch_trace(const SceneView& sc, const RenderArgs& ra, bool exact, bool counted, float* d_samples,
+hipError_t launch_trace(const SceneView& sc, const RenderArgs& ra_in, bool exact, bool counted, float* d_samples,
                         unsigned long long* d_stats, uint32_t* d_work_counter, float* d_mail, hipStream_t stream)
 {
-    if (ra.n_items == 0u) return hipSuccess;
+    if (ra_in.n_items == 0u) return hipSuccess;
+    RenderArgs ra = ra_in;
+    set_item_order(ra, 0u);
     hipError_t e = hipMemsetAsync(d_work_counter, 0, sizeof(uint32_t), stream);
     if (e != hipSuccess) return e;
     // Tuning knobs for experiments; the defaults are the shipped configuration.
@@ -651,7 +825,15 @@ hipError_t launch_trace(const SceneView& sc, const RenderArgs& ra, bool exact, b
 #undef SRT_LAUNCH_MESH
         return hipGetLastError();
     }
-#define SRT_LAUNCH(E, C, S) hipLaunchKernelGGL((trace_kernel<E, C, S>), grid, block, 0, stream, sc, ra, s, d_stats, d_work_counter, mailboxes, vote, chunk)
+    const int share = allow_fork && (uint32_t)ra.mode == MODE_COLOR ? 1 : 0;
+    static const uint32_t stretch_knob = std::getenv("SRT_LAST_STRETCH") ? (uint32_t)std::atoi(std::getenv("SRT_LAST_STRETCH")) : 512u;
+    const uint32_t last_stretch = blocks * (uint32_t)kWaves * stretch_knob;   // items, counted from the end of the launch
+    // The last samples of the pass in scattered order (with a stride that spreads the 64 lanes of a draw over the whole
+    // picture): measured on the default scene at 1080p, a sample costs 0.89 ms in block order and 1.08 ms scattered, but
+    // a launch that ends in block order runs 1.8 ms longer than its samples take.
+    static const uint32_t scatter_samples = std::getenv("SRT_SCATTER_SAMPLES") ? (uint32_t)std::atoi(std::getenv("SRT_SCATTER_SAMPLES")) : kScatterSamples;
+    set_item_order(ra, scatter_samples);
+#define SRT_LAUNCH(E, C, S) hipLaunchKernelGGL((trace_kernel<E, C, S>), grid, block, 0, stream, sc, ra, s, d_stats, d_work_counter, mailboxes, vote, chunk, share, last_stretch)
     if (exact) {
         if (counted) { if (small) SRT_LAUNCH(true, true, true); else SRT_LAUNCH(true, true, false); }
         else { if (small) SRT_LAUNCH(true, false, true); else SRT_LAUNCH(true, false, false); }

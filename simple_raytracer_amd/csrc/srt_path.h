@@ -39,13 +39,23 @@ struct Lane {
 
 // Work item -> (pixel, sample).  Items enumerate 64-pixel blocks (8x8 pixels of one tile), and inside
 // a block all samples of the pass, 64 pixels at a time, so that 64 consecutive items are one 8x8
-// pixel block at one sample index.  Returns false for padding pixels of edge tiles.
+// pixel block at one sample index; the last samples of a pass may instead come one after the other, and inside a
+// sample 64 pixels from 64 different blocks at a time (RenderArgs::coherent).  Returns false for padding pixels of edge tiles.
 SRT_HD bool item_start(Lane& ln, const RenderArgs& ra, uint32_t item, const float* unit)
 {
-    uint32_t per_block = 64u * ra.sample_count;
-    uint32_t blk = item / per_block, r = item - blk * per_block;
-    uint32_t s_local = r >> 6, k = r & 63u;
-    uint32_t wp = blk * 64u + k;
+    uint32_t s_local, wp;
+    const uint32_t n_coherent = ra.n_work * ra.coherent;
+    if (item < n_coherent) {
+        uint32_t per_block = 64u * ra.coherent;
+        uint32_t blk = item / per_block, r = item - blk * per_block;
+        s_local = r >> 6;
+        wp = blk * 64u + (r & 63u);
+    } else {
+        uint32_t rest = item - n_coherent, s = rest / ra.n_work;
+        uint32_t j = rest - s * ra.n_work, k = j & 63u;
+        s_local = ra.coherent + s;
+        wp = (((j >> 6) + k * ra.scatter) % (ra.n_work >> 6)) * 64u + k;
+    }
     int32_t x, y;
     uint32_t unused;
     if (!work_to_pixel(ra, wp, x, y, unused)) return false;

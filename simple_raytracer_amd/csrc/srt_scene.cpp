@@ -622,6 +622,7 @@ int make_render_args(const srt_render_params* p, const Camera& cam, RenderArgs& 
     ra.sample_first = 0u;
     ra.sample_count = (uint32_t)p->samples;
     ra.n_items = 0u;  // set per pass by the launcher
+    ra.coherent = ra.sample_count; ra.scatter = 0u;  // set per pass by the launcher
     return SRT_OK;
 }
 

@@ -154,6 +154,7 @@ int srt_render(srt_ctx* c, const srt_render_params* p, uint32_t* out)
     for (uint32_t s0 = 0; s0 < (uint32_t)ra.samples; s0 += per_pass) {
         ra.sample_first = s0;
         ra.sample_count = std::min<uint32_t>(per_pass, (uint32_t)ra.samples - s0);
+        set_item_order(ra, 2u);   // as the GPU launcher does for scenes without a traversal stack
         ra.n_items = ra.n_work * ra.sample_count;
         std::vector<std::thread> pool;
         for (unsigned t = 0; t < n; t++) {

@@ -38,7 +38,7 @@ PEAK_HBM_GBS = 8000.0      # MI355X HBM3E peak
 # `--pmc WRITE_SIZE` passes over this command (tools/pmc_traffic.sh; the counters are in KiB, and FETCH_SIZE is
 # doubled, the correction for gfx950).  They are not re-measured by a normal run: a counter pass needs the profiler.
 # Almost all of it is private-memory traffic of the ray-tree frames below the levels kept in LDS, plus 0.4 GB of samples.
-MEASURED_TRAFFIC_KIB = {"bvhnode": (2687693.8, 11673297.5)}   # (FETCH_SIZE, WRITE_SIZE) of trace_kernel<true,false,true>
+MEASURED_TRAFFIC_KIB = {"bvhnode": (3106033.2, 12299515.6)}   # (FETCH_SIZE, WRITE_SIZE) of trace_kernel<true,false,true>
 
 # Algorithmic work per event: bytes fetched / FP32 operations (add, sub, mul, div, sqrt, min, max, compare = 1 each)
 # of the reference algorithm, excluding work the GPU legitimately skips.
@@ -184,7 +184,7 @@ def main():
             fetch_kib, write_kib = MEASURED_TRAFFIC_KIB[args.world_kind]
             traffic = int((2.0 * fetch_kib + write_kib) * 1024)
         roofline.update({"traffic": traffic, "traffic_source": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command, 2*FETCH+WRITE "
-                         "(profiles/r1_v3_pmc_traffic.txt); constant, not re-measured in this run", "kernel": "trace_kernel", "avg_launch_ms": round(avg_ms, 4),
+                         "(profiles/r1_v6_pmc_traffic.txt); constant, not re-measured in this run", "kernel": "trace_kernel", "avg_launch_ms": round(avg_ms, 4),
                          "algorithmic_flops_per_launch": aflops, "algorithmic_bytes_per_launch": abytes,
                          "algorithmic_gbs": round(gbs, 2), "algorithmic_tflops": round(tflops, 3)})
         line = {

@@ -819,6 +819,8 @@ hipError_t launch_trace(const SceneView& sc, const RenderArgs& ra_in, bool exact
     static const bool allow_fork = !std::getenv("SRT_NO_SUBTREE_SHARING");
     float4* mailboxes = allow_fork ? reinterpret_cast<float4*>(d_mail) : nullptr;
     if (!stackless) {
+        static const uint32_t mesh_scatter = std::getenv("SRT_MESH_SCATTER_SAMPLES") ? (uint32_t)std::atoi(std::getenv("SRT_MESH_SCATTER_SAMPLES")) : 0u;
+        set_item_order(ra, mesh_scatter);
 #define SRT_LAUNCH_MESH(E, C) hipLaunchKernelGGL((mesh_trace_kernel<E, C>), grid, block, 0, stream, sc, ra, s, d_stats, d_work_counter, mailboxes, walk_vote, walk_rounds, walk_steps, chunk)
         if (exact) { if (counted) SRT_LAUNCH_MESH(true, true); else SRT_LAUNCH_MESH(true, false); }
         else { if (counted) SRT_LAUNCH_MESH(false, true); else SRT_LAUNCH_MESH(false, false); }

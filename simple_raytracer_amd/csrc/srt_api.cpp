@@ -105,7 +105,7 @@ int collect_stats(srt_ctx* c)
     SRT_HIP(c, hipStreamSynchronize(c->stream));
 #ifdef SRT_TIMELINE
     if (const char* path = std::getenv("SRT_TIMELINE_FILE")) {
-        std::vector<unsigned long long> tl(3072 * 4);
+        std::vector<unsigned long long> tl(4096 * 4);
         hipMemcpy(tl.data(), reinterpret_cast<char*>(c->d_mail) + srt::trace_timeline_offset(), tl.size() * 8, hipMemcpyDeviceToHost);
         if (FILE* f = std::fopen(path, "wb")) { std::fwrite(tl.data(), 8, tl.size(), f); std::fclose(f); }
     }

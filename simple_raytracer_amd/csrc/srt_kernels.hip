@@ -54,6 +54,15 @@ __device__ __forceinline__ uint32_t lanes_below(unsigned long long mask)
     return __builtin_amdgcn_mbcnt_hi((uint32_t)(mask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mask, 0u));
 }
 
+// Items to draw next from the global counter, given where the last draw ended: `chunk` while there is plenty left,
+// then an ever smaller share of what is left (down to one item per lane), so that no wavefront ends the launch with
+// a long range of its own.  A range of items that all hit a mesh costs a wavefront milliseconds.
+__device__ __forceinline__ uint32_t next_draw(uint32_t left, uint32_t guide, uint32_t chunk)
+{
+    const uint32_t share = (left / guide) & ~63u;      // guide = 2 x the wavefronts of the grid
+    return share >= chunk ? chunk : (share < 64u ? 64u : share);
+}
+
 // Profiler of the counting builds: shader-clock cycles between consecutive marks, by the part that ended.
 struct ClockProf {
     unsigned long long cyc[PROF_SLOTS] = {};
@@ -299,7 +308,7 @@ __device__ __forceinline__ void copy_words(q4* dst, const q4* src, uint32_t n)
 template <bool EXACT, bool COUNT, bool SMALL>
 __global__ void __launch_bounds__(kBlock, SMALL ? SRT_WAVES_PER_SIMD : SRT_WAVES_PER_SIMD_BIG) trace_kernel(SceneView gsc, RenderArgs ra, f3* __restrict__ samples,
                                                        unsigned long long* __restrict__ stats, uint32_t* __restrict__ work_counter,
-                                                       float4* __restrict__ mail /* -DSRT_TIMELINE builds only */, int trace_vote, uint32_t chunk, int share, uint32_t last_stretch)
+                                                       float4* __restrict__ mail /* -DSRT_TIMELINE builds only */, int trace_vote, uint32_t chunk, int share, uint32_t guide)
 {
     __shared__ float lds_frames[SMALL ? kWaves * kLdsFrameLevels * 14 * 64 : 1];
     __shared__ uint32_t lds_pair[kWaves * 64];   // handing over subtrees: giver lane by rank
@@ -380,9 +389,9 @@ __global__ void __launch_bounds__(kBlock, SMALL ? SRT_WAVES_PER_SIMD : SRT_WAVES
                     }
                     next = base;
                     end = base + draw < ra.n_items ? base + draw : ra.n_items;
-                    // the last stretch of the block-ordered items is drawn in small pieces, so that no wavefront is left
-                    // with a pile of deep trees of its own when the others move on to the scattered items
-                    draw = ra.n_work * ra.coherent - end < last_stretch ? 64u : chunk;
+                    // towards the end of the block-ordered items, and again towards the end of the scattered ones
+                    const uint32_t n_coherent = ra.n_work * ra.coherent;
+                    draw = next_draw((end < n_coherent ? n_coherent : ra.n_items) - end, guide, chunk);
                 }
                 uint32_t avail = end - next, want = (uint32_t)__popcll(idle);
                 uint32_t rank = lanes_below(idle);
@@ -498,8 +507,8 @@ __global__ void __launch_bounds__(kBlock, SMALL ? SRT_WAVES_PER_SIMD : SRT_WAVES
     }
 
 #ifdef SRT_TIMELINE
-    if (lane == 0u) {
-        unsigned long long* rec = reinterpret_cast<unsigned long long*>(mail + (size_t)1000 * kWaves * kMailPerWave) + ((size_t)blockIdx.x * kWaves + wave) * 4;
+    if (lane == 0u && mail != nullptr) {
+        unsigned long long* rec = reinterpret_cast<unsigned long long*>(mail + (size_t)1100 * kWaves * kMailPerWave) + ((size_t)blockIdx.x * kWaves + wave) * 4;
         rec[0] = tl_start; rec[1] = tl_dry; rec[2] = wall_clock64(); rec[3] = tl_trips;
     }
 #endif
@@ -552,7 +561,7 @@ constexpr int kWalkVote = 16, kWalkRounds = 1 << 24, kWalkSteps = 2;
 template <bool EXACT, bool COUNT>
 __global__ void __launch_bounds__(kBlock, SRT_WAVES_PER_SIMD_MESH) mesh_trace_kernel(SceneView sc, RenderArgs ra, f3* __restrict__ samples,
                                                             unsigned long long* __restrict__ stats, uint32_t* __restrict__ work_counter,
-                                                            float4* __restrict__ mail, int walk_vote, int rounds, int steps, uint32_t chunk)
+                                                            float4* __restrict__ mail, int walk_vote, int rounds, int steps, uint32_t chunk, uint32_t guide)
 {
     __shared__ uint32_t lds_stack[kWaves * STACK_DEPTH * 64];
     __shared__ uint32_t lds_pair[kWaves * 64];   // handing over subtrees: giver lane by rank
@@ -562,6 +571,10 @@ __global__ void __launch_bounds__(kBlock, SRT_WAVES_PER_SIMD_MESH) mesh_trace_ke
     if (threadIdx.x < (uint32_t)UNIT_TABLE) unit[threadIdx.x] = (float)((int)threadIdx.x - 100) / 100.0f;
     __syncthreads();
 
+#ifdef SRT_TIMELINE
+    const unsigned long long tl_start = wall_clock64();
+    unsigned long long tl_dry = 0ull, tl_trips = 0ull;
+#endif
     Lane ln;
     Frame frame_mem[FRAME_SLOTS];
     PrivateFrames frames;
@@ -585,7 +598,7 @@ __global__ void __launch_bounds__(kBlock, SRT_WAVES_PER_SIMD_MESH) mesh_trace_ke
 
     uint32_t sect[4] = {0u, 0u, 0u, 0u};
     typename std::conditional<COUNT, ClockProf, NoProf>::type prof;
-    uint32_t next = 0u, end = 0u;
+    uint32_t next = 0u, end = 0u, draw = chunk;
     bool dry = false;
 
     // the lane's next state after a per-lane function returned LANE_*; `ret` is the sample's colour for LANE_IDLE
@@ -607,6 +620,9 @@ __global__ void __launch_bounds__(kBlock, SRT_WAVES_PER_SIMD_MESH) mesh_trace_ke
     for (;;) {
         if constexpr (COUNT) prof.start();
         // ---- subtrees that other lanes traced for this one; subtrees for idle lanes once there are no new items
+#ifdef SRT_TIMELINE
+        if (dry) tl_trips++; else tl_trips += 1ull << 32;
+#endif
         poll_mailbox(ln, phase, fork, my_mail, lane);
         trip++;
         if (my_mail != nullptr && dry && (trip % (uint32_t)kForkEvery) == 0u && (uint32_t)ra.mode == MODE_COLOR) {
@@ -650,11 +666,18 @@ __global__ void __launch_bounds__(kBlock, SRT_WAVES_PER_SIMD_MESH) mesh_trace_ke
                 if (next >= end) {
                     if (dry) break;
                     uint32_t base = 0u;
-                    if (lane == 0u) base = atomicAdd(work_counter, chunk);
+                    if (lane == 0u) base = atomicAdd(work_counter, draw);
                     base = __builtin_amdgcn_readfirstlane(base);
-                    if (base >= ra.n_items) { dry = true; break; }
+                    if (base >= ra.n_items) {
+                        dry = true;
+#ifdef SRT_TIMELINE
+                        tl_dry = wall_clock64();
+#endif
+                        break;
+                    }
                     next = base;
-                    end = base + chunk < ra.n_items ? base + chunk : ra.n_items;
+                    end = base + draw < ra.n_items ? base + draw : ra.n_items;
+                    draw = next_draw(ra.n_items - end, guide, chunk);
                 }
                 uint32_t avail = end - next, want = (uint32_t)__popcll(idle);
                 uint32_t rank = lanes_below(idle);
@@ -696,6 +719,12 @@ __global__ void __launch_bounds__(kBlock, SRT_WAVES_PER_SIMD_MESH) mesh_trace_ke
         }
     }
 
+#ifdef SRT_TIMELINE
+    if (lane == 0u && mail != nullptr) {
+        unsigned long long* rec = reinterpret_cast<unsigned long long*>(mail + (size_t)1100 * kWaves * kMailPerWave) + ((size_t)blockIdx.x * kWaves + wave) * 4;
+        rec[0] = tl_start; rec[1] = tl_dry; rec[2] = wall_clock64(); rec[3] = tl_trips;
+    }
+#endif
     unsigned long long v0 = wave_sum(ln.rays_path), v1 = wave_sum(ln.rays_shadow), v2 = wave_sum(ln.hit_nodes);
     if (lane == 0u) {
         atomicAdd(&stats[0], v0);
@@ -811,6 +840,8 @@ hipError_t launch_trace(const SceneView& sc, const RenderArgs& ra_in, bool exact
         uint32_t share = (ra.n_items / (blocks * (uint32_t)kWaves)) / 8u;
         chunk = share >= kChunk ? kChunk : (share < 64u ? 64u : (share & ~63u));
     }
+    static const uint32_t guide_knob = std::getenv("SRT_GUIDE") ? (uint32_t)std::atoi(std::getenv("SRT_GUIDE")) : 2u;
+    const uint32_t guide = guide_knob != 0u ? blocks * (uint32_t)kWaves * guide_knob : 1u;   // 1: every draw is `chunk` items
     f3* s = reinterpret_cast<f3*>(d_samples);
     // Scenes whose tree is walked with a stack get the kernel that schedules traversal in quanta.
     static const int walk_vote = std::getenv("SRT_WALK_VOTE") ? std::atoi(std::getenv("SRT_WALK_VOTE")) : kWalkVote;
@@ -821,21 +852,19 @@ hipError_t launch_trace(const SceneView& sc, const RenderArgs& ra_in, bool exact
     if (!stackless) {
         static const uint32_t mesh_scatter = std::getenv("SRT_MESH_SCATTER_SAMPLES") ? (uint32_t)std::atoi(std::getenv("SRT_MESH_SCATTER_SAMPLES")) : 0u;
         set_item_order(ra, mesh_scatter);
-#define SRT_LAUNCH_MESH(E, C) hipLaunchKernelGGL((mesh_trace_kernel<E, C>), grid, block, 0, stream, sc, ra, s, d_stats, d_work_counter, mailboxes, walk_vote, walk_rounds, walk_steps, chunk)
+#define SRT_LAUNCH_MESH(E, C) hipLaunchKernelGGL((mesh_trace_kernel<E, C>), grid, block, 0, stream, sc, ra, s, d_stats, d_work_counter, mailboxes, walk_vote, walk_rounds, walk_steps, chunk, guide)
         if (exact) { if (counted) SRT_LAUNCH_MESH(true, true); else SRT_LAUNCH_MESH(true, false); }
         else { if (counted) SRT_LAUNCH_MESH(false, true); else SRT_LAUNCH_MESH(false, false); }
 #undef SRT_LAUNCH_MESH
         return hipGetLastError();
     }
     const int share = allow_fork && (uint32_t)ra.mode == MODE_COLOR ? 1 : 0;
-    static const uint32_t stretch_knob = std::getenv("SRT_LAST_STRETCH") ? (uint32_t)std::atoi(std::getenv("SRT_LAST_STRETCH")) : 512u;
-    const uint32_t last_stretch = blocks * (uint32_t)kWaves * stretch_knob;   // items, counted from the end of the launch
     // The last samples of the pass in scattered order (with a stride that spreads the 64 lanes of a draw over the whole
     // picture): measured on the default scene at 1080p, a sample costs 0.89 ms in block order and 1.08 ms scattered, but
     // a launch that ends in block order runs 1.8 ms longer than its samples take.
     static const uint32_t scatter_samples = std::getenv("SRT_SCATTER_SAMPLES") ? (uint32_t)std::atoi(std::getenv("SRT_SCATTER_SAMPLES")) : kScatterSamples;
     set_item_order(ra, scatter_samples);
-#define SRT_LAUNCH(E, C, S) hipLaunchKernelGGL((trace_kernel<E, C, S>), grid, block, 0, stream, sc, ra, s, d_stats, d_work_counter, mailboxes, vote, chunk, share, last_stretch)
+#define SRT_LAUNCH(E, C, S) hipLaunchKernelGGL((trace_kernel<E, C, S>), grid, block, 0, stream, sc, ra, s, d_stats, d_work_counter, mailboxes, vote, chunk, share, guide)
     if (exact) {
         if (counted) { if (small) SRT_LAUNCH(true, true, true); else SRT_LAUNCH(true, true, false); }
         else { if (small) SRT_LAUNCH(true, false, true); else SRT_LAUNCH(true, false, false); }
@@ -847,7 +876,7 @@ hipError_t launch_trace(const SceneView& sc, const RenderArgs& ra_in, bool exact
     return hipGetLastError();
 }
 
-size_t trace_timeline_offset() { return (size_t)1000 * kWaves * kMailPerWave * sizeof(float4); }
+size_t trace_timeline_offset() { return (size_t)1100 * kWaves * kMailPerWave * sizeof(float4); }
 size_t trace_mail_bytes() { return (size_t)kMaxBlocks * kWaves * kMailPerWave * sizeof(float4); }
 
 hipError_t launch_resolve(const RenderArgs& ra, const float* d_samples, float* d_running, uint32_t* d_out, bool first_pass, bool last_pass,

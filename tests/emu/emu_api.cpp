@@ -188,6 +188,29 @@ int srt_render(srt_ctx* c, const srt_render_params* p, uint32_t* out)
     return SRT_OK;
 }
 int srt_render_counted(srt_ctx* c, const srt_render_params* p, uint32_t* out) { return srt_render(c, p, out); }
+
+// Test hook (not part of include/srt.h): the item order of one pass.  For every work item of a pass over all of
+// p->samples with the last `scatter_samples` in scattered order: slots[item] = its sample-buffer slot, pixels[item] =
+// x + y * width, or 0xFFFFFFFF for a padding pixel of an edge tile.  Returns the number of items.
+int64_t srt_emu_item_order(srt_ctx* c, const srt_render_params* p, uint32_t scatter_samples, uint32_t* slots, uint32_t* pixels, uint64_t capacity)
+{
+    RenderArgs ra;
+    if (make_render_args(p, c->cam, ra, c->error) != SRT_OK) return -1;
+    ra.sample_first = 0u;
+    ra.sample_count = (uint32_t)ra.samples;
+    set_item_order(ra, scatter_samples);
+    ra.n_items = ra.n_work * ra.sample_count;
+    if ((uint64_t)ra.n_items > capacity) return -2;
+    float unit[UNIT_TABLE];
+    fill_unit_table(unit);
+    for (uint32_t item = 0; item < ra.n_items; item++) {
+        Lane ln;
+        const bool real = item_start(ln, ra, item, unit);
+        slots[item] = real ? ln.slot : 0xFFFFFFFFu;
+        pixels[item] = real ? ln.key.pixel : 0xFFFFFFFFu;
+    }
+    return (int64_t)ra.n_items;
+}
 int srt_get_stats(srt_ctx* c, srt_stats* out) { *out = c->stats; return SRT_OK; }
 int64_t srt_local_pixels(const srt_render_params* p) { return output_pixels(p); }
 

@@ -63,3 +63,44 @@ import random_scenes  # noqa: E402
 def test_random_scene_matches_oracle(emu, oracle, seed):
     lsb, npx, same_counts, what = random_scenes.run(emu, oracle, seed)
     assert (lsb, npx) == (0, 0) and same_counts, what
+
+
+@pytest.mark.parametrize("width,height,samples,scatter,rank,world", [
+    (64, 36, 1, 0, 0, 1), (64, 36, 1, 2, 0, 1), (64, 36, 5, 2, 0, 1), (70, 45, 4, 1, 0, 1), (70, 45, 3, 3, 0, 1),
+    (200, 120, 3, 2, 1, 3), (33, 17, 2, 2, 0, 2), (640, 360, 3, 2, 0, 1)])
+def test_item_order_covers_every_pixel_and_sample_once(emu, width, height, samples, scatter, rank, world):
+    """Whatever the order of the work items (blocks first, the last samples scattered), a pass visits every
+    (pixel, sample) of the rank once, and every slot of its sample buffer at most once."""
+    import ctypes as C
+
+    import helpers
+    import numpy as np
+    w, l, cam = helpers.default_spec().host(width, height)
+    emu.set_scene(w, l, cam)
+    kw = dict(samples=samples, max_depth=2)
+    if world > 1:
+        kw.update(layout=1, tile_w=32, tile_h=32, rank=rank, world_size=world)
+    p = emu.params(width, height, **kw)
+    fn = emu._lib.srt_emu_item_order
+    fn.restype = C.c_int64
+    cap = 1 << 22
+    slots, pixels = np.empty(cap, np.uint32), np.empty(cap, np.uint32)
+    n = fn(emu._ctx, C.byref(p), C.c_uint32(scatter), slots.ctypes.data_as(C.c_void_p), pixels.ctypes.data_as(C.c_void_p), C.c_uint64(cap))
+    assert n > 0 and n % samples == 0
+    slots, pixels = slots[:n], pixels[:n]
+    real = slots != 0xFFFFFFFF
+    n_work = n // samples
+    assert len(np.unique(slots[real])) == real.sum()                      # no slot twice
+    assert slots[real].max() < n
+    sample_of = slots[real] // n_work
+    pairs = pixels[real].astype(np.uint64) * samples + sample_of
+    assert len(np.unique(pairs)) == len(pairs)                            # no (pixel, sample) twice
+    if world == 1:
+        assert len(pairs) == width * height * samples                     # and none missing
+    else:
+        tiles_x, tiles_y = (width + 31) // 32, (height + 31) // 32
+        mine = 0
+        for t in range(rank, tiles_x * tiles_y, world):
+            tx, ty = t % tiles_x, t // tiles_x
+            mine += (min(32, width - tx * 32)) * (min(32, height - ty * 32))
+        assert len(pairs) == mine * samples

@@ -32,7 +32,7 @@ struct srt_ctx {
     size_t out_capacity = 0;  // pixels
     unsigned long long* d_stats = nullptr;
     uint32_t* d_counter = nullptr;        // work counter of the persistent trace kernel
-    float* d_mail = nullptr;              // mailboxes of the mesh kernel (subtree colours handed between lanes)
+    float* d_mail = nullptr;              // scratch of -DSRT_TIMELINE builds (per-wavefront clock records)
     float* d_samples = nullptr;           // per-(sample, pixel) colours of one pass, 12 bytes each
     size_t samples_capacity = 0;          // bytes
     float* d_running = nullptr;           // per-pixel running sums, only for renders that need several passes

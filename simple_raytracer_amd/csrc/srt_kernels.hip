@@ -78,14 +78,16 @@ struct ClockProf {
 
 // Sharing one ray tree between lanes.  Once the global counter is exhausted, a wavefront whose lanes are partly idle
 // lets busy lanes hand subtrees to the idle ones: a lane gives away child 1 or 2 (the metal / reflect child, whose ray
-// is stored in the frame) of its shallowest pending node that still has one, one subtree per round, so after a few
-// rounds it keeps only the first-child spine of its tree.  The helper lane traces the subtree as a work item of its
-// own -- same pixel, sample and node id, hence the same random numbers and the same colour -- and leaves the colour in
-// the giver's mailbox (global memory, one slot per lane, frame level and child); the giver consumes it where it would
-// have started that child (lane_return -> LANE_WAIT -> resumed as RETURN).  Helpers give away parts of their subtrees
-// in turn, so one deep tree (255 nodes at depth 8 with two children per node, 3,280 with three) spreads over the
-// wavefront instead of keeping one lane busy long after everything else has finished: the time of a tree is then
-// set by its depth, not its node count.  Results and ray counts do not change.
+// is stored in the frame) of its shallowest pending node that still has one, one subtree per trip, so after a few
+// trips it keeps only the first-child spine of its tree.  The helper lane traces the subtree as a work item of its
+// own -- same pixel, sample and node id, hence the same random numbers and the same colour.  When it is done it keeps
+// the colour (LANE_DELIVER) until the giver has reached the point where it would have started that child and waits for
+// it (lane_return -> LANE_WAIT); then the colour travels by readlane and the giver resumes as if the child had just
+// returned (LANE_RETURN).  No memory is involved.  Helpers give away parts of their subtrees in turn, so one deep tree
+// (255 nodes at depth 8 with two children per node, 3,280 with three) spreads over the wavefront instead of keeping
+// one lane busy long after everything else has finished: the time of a tree is then set by its depth, not its node
+// count.  Results and ray counts do not change.  The children that a lane can still give away are kept in a bit mask
+// (`open`, bit 2*level + child - 1) instead of being searched for in the frames.
 constexpr int kForkLevels = 8;         // frames at levels below this can give children away
 struct TreeFork {
     uint32_t given;    // bit 2*level + child - 1: that child of the frame at `level` is with another lane
@@ -93,113 +95,9 @@ struct TreeFork {
     __device__ __forceinline__ bool donated(int32_t lvl, uint32_t child) const { return lvl < kForkLevels && ((given >> (2 * lvl + (int32_t)child - 1)) & 1u) != 0u; }
     __device__ __forceinline__ void wait_for(uint32_t child) { wait = child; }
 };
-constexpr int kForkEvery = 4;          // mesh kernel: look for subtrees to hand over on every kForkEvery-th trip of the main loop
 constexpr int kForkMinDepth = 2;       // only subtrees that can still grow (remaining depth >= this)
-constexpr size_t kMailPerWave = (size_t)kForkLevels * 2 * 64;   // float4 entries: [2*level + child - 1][lane]
+constexpr size_t kMailPerWave = 64;     // -DSRT_TIMELINE builds: float4 entries of scratch per wavefront of the grid
 
-// A lane in LANE_WAIT: has the colour of the child it waits for arrived?  Then it continues in LANE_RETURN as if that
-// child had just returned.
-__device__ __forceinline__ void poll_mailbox(Lane& ln, int& phase, TreeFork& fork, float4* my_mail, uint32_t lane)
-{
-    if (phase != LANE_WAIT) return;
-    const uint32_t c = fork.wait, bit = 2u * (uint32_t)(ln.level - 1) + c - 1u;
-    float4* slot = &my_mail[(size_t)bit * 64 + lane];
-    if (__hip_atomic_load(&slot->w, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) == 1.0f) {
-        ln.former = mk3(__hip_atomic_load(&slot->x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT),
-                        __hip_atomic_load(&slot->y, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT),
-                        __hip_atomic_load(&slot->z, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
-        ln.key.node = ln.key.node * 4u + c + 1u;
-        fork.given &= ~(1u << bit);
-        phase = LANE_RETURN;
-    }
-}
-
-// The colour of a finished tree: into the sample buffer, or -- for a subtree traced for another lane -- into that
-// lane's mailbox (colour first, then the flag).
-__device__ __forceinline__ void deliver_colour(const Lane& ln, f3 ret, int32_t& deliver, float4* my_mail, f3* __restrict__ samples)
-{
-    if (deliver >= 0) {
-        float4* slot = &my_mail[(size_t)(deliver >> 8) * 64 + (size_t)(deliver & 63)];
-        __hip_atomic_store(&slot->x, ret.x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        __hip_atomic_store(&slot->y, ret.y, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        __hip_atomic_store(&slot->z, ret.z, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        __hip_atomic_store(&slot->w, 1.0f, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
-        deliver = -1;
-    } else {
-        samples[ln.slot] = ret;
-    }
-}
-
-// Wave-wide: pairs lanes that can give a subtree away with idle lanes.  Returns true on the lanes that took one; their
-// Lane then holds the subtree's root query (key, qo, qd, qtmin, depth, level 0) and `deliver` says where its colour
-// goes.  Phases are the LANE_* values (idle lanes are LANE_IDLE, waiting lanes LANE_WAIT).
-template <class FRAMES>
-__device__ __forceinline__ bool share_subtrees(Lane& ln, int phase, const FRAMES& frames, TreeFork& fork, int32_t& deliver, float4* my_mail,
-                                               uint32_t* my_pair, const SceneView& sc, const RenderArgs& ra, uint32_t lane, uint32_t& handed)
-{
-    const unsigned long long idle_mask = __ballot(phase == LANE_IDLE);
-    if (idle_mask == 0ull) return false;
-    bool cand = false;
-    uint32_t g_bit = 0u, g_node = 0u;
-    int32_t g_depth = 0;
-    f3 g_point = mk3(0.0f, 0.0f, 0.0f), g_dir = mk3(0.0f, 0.0f, 0.0f);
-    if (phase != LANE_IDLE && ln.level >= 1) {
-        // A waiting lane holds the id of its deepest frame's node, any other lane the id of a node one level below.
-        const int32_t below = phase == LANE_WAIT ? ln.level - 1 : ln.level;
-        const int32_t j1 = ln.level - 1 < kForkLevels - 1 ? ln.level - 1 : kForkLevels - 1;
-        for (int32_t j = 0; j <= j1 && !cand; j++) {
-            const Frame f = frames.load(j);
-            const int32_t child_depth = (int32_t)(f.meta >> 24);
-            if (child_depth < kForkMinDepth) break;      // deeper frames have less depth left still
-            const float metal = sc.materials[2u * (f.meta & 0x00FFFFFFu)].w;
-            // node id of frame j and the child of it that is running (or, at a waiting lane's deepest frame, waited for)
-            const uint32_t node_j = ln.key.node >> (2 * (below - j));
-            const uint32_t running = j == below ? fork.wait : ((ln.key.node >> (2 * (below - 1 - j))) & 3u) - 1u;
-            for (uint32_t c = 2u; c >= 1u && !cand; c--) {
-                const bool exists = c == 1u ? (metal != 0.0f) : (metal != 1.0f);
-                const uint32_t bit = 2u * (uint32_t)j + c - 1u;
-                if (c > running && exists && ((fork.given >> bit) & 1u) == 0u) {
-                    cand = true; g_bit = bit; g_node = node_j * 4u + c + 1u; g_depth = child_depth; g_point = f.point; g_dir = f.refl;
-                }
-            }
-        }
-    }
-    const unsigned long long cand_mask = __ballot(cand);
-    const uint32_t n_cand = (uint32_t)__popcll(cand_mask), n_idle = (uint32_t)__popcll(idle_mask);
-    const uint32_t n_pairs = n_cand < n_idle ? n_cand : n_idle;
-    if (n_pairs == 0u) return false;
-    handed += n_pairs;
-    const uint32_t rank_c = lanes_below(cand_mask), rank_i = lanes_below(idle_mask);
-    const bool gives = cand && rank_c < n_pairs, takes = phase == LANE_IDLE && rank_i < n_pairs;
-    if (gives) my_pair[rank_c] = lane;
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-    __builtin_amdgcn_wave_barrier();
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-    const int src = takes ? (int)my_pair[rank_i] : (int)lane;
-    const uint32_t s_pixel = (uint32_t)__shfl((int)ln.key.pixel, src, 64), s_sample = (uint32_t)__shfl((int)ln.key.sample, src, 64);
-    const uint32_t s_node = (uint32_t)__shfl((int)g_node, src, 64), s_bit = (uint32_t)__shfl((int)g_bit, src, 64);
-    const int32_t s_depth = __shfl(g_depth, src, 64);
-    const f3 s_point = mk3(__shfl(g_point.x, src, 64), __shfl(g_point.y, src, 64), __shfl(g_point.z, src, 64));
-    const f3 s_dir = mk3(__shfl(g_dir.x, src, 64), __shfl(g_dir.y, src, 64), __shfl(g_dir.z, src, 64));
-    if (gives) {
-        fork.given |= 1u << g_bit;
-        __hip_atomic_store(&my_mail[(size_t)g_bit * 64 + lane].w, 0.0f, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    }
-    if (takes) {
-        ln.key.seed = ra.seed; ln.key.pixel = s_pixel; ln.key.sample = s_sample;
-        ln.key.node = s_node;
-        ln.qo = s_point; ln.qd = s_dir; ln.qtmin = 0.01f;
-        ln.depth = s_depth; ln.level = 0;
-        fork.given = 0u; fork.wait = 0u;
-        deliver = src | (int32_t)(s_bit << 8);
-    }
-    return takes;
-}
-
-// trace_kernel's closing loop shares trees the same way but without memory in between: a helper that has its subtree's
-// colour keeps it (LANE_DELIVER) until the giver waits for exactly that child, and then it travels by readlane.  The
-// children that a lane can still give away are kept in a bit mask (`open`, bit 2*level + child - 1) instead of being
-// searched for in the frames.
 enum { LANE_DELIVER = 5 };
 
 // `open` of a lane that enters the closing loop in the middle of a tree
@@ -247,7 +145,7 @@ __device__ __forceinline__ void rendezvous(Lane& ln, int& phase, TreeFork& fork,
 // Pairs lanes that can give a child away with idle lanes; returns true on the lanes that took one (see share_subtrees).
 template <class FRAMES>
 __device__ __forceinline__ bool share_open_children(Lane& ln, int phase, const FRAMES& frames, TreeFork& fork, uint32_t& open, int32_t& deliver,
-                                                    uint32_t* my_pair, const RenderArgs& ra, uint32_t lane)
+                                                    uint32_t* my_pair, const RenderArgs& ra, uint32_t lane, uint32_t& handed)
 {
     const unsigned long long idle_mask = __ballot(phase == LANE_IDLE);
     const bool cand = phase != LANE_IDLE && phase != LANE_DELIVER && open != 0u;
@@ -255,6 +153,7 @@ __device__ __forceinline__ bool share_open_children(Lane& ln, int phase, const F
     const uint32_t n_cand = (uint32_t)__popcll(cand_mask), n_idle = (uint32_t)__popcll(idle_mask);
     const uint32_t n_pairs = n_cand < n_idle ? n_cand : n_idle;
     if (n_pairs == 0u) return false;
+    handed += n_pairs;
     const uint32_t rank_c = lanes_below(cand_mask), rank_i = lanes_below(idle_mask);
     const bool gives = cand && rank_c < n_pairs, takes = phase == LANE_IDLE && rank_i < n_pairs;
     uint32_t g_bit = 0u, g_node = 0u;
@@ -351,6 +250,7 @@ __global__ void __launch_bounds__(kBlock, SMALL ? SRT_WAVES_PER_SIMD : SRT_WAVES
     uint32_t next = 0u, end = 0u;  // wave-uniform: the wavefront's private range of items
     bool dry = false;              // wave-uniform: the global counter is exhausted
     uint32_t draw = chunk;         // wave-uniform: items per draw from the global counter
+    uint32_t handed = 0u;          // wave-uniform: subtrees that changed lanes in the closing loop
     unsigned long long t_dry = 0ull;   // counting builds: wall clock (100 MHz) when this wavefront found the counter exhausted
 
     for (;;) {
@@ -462,7 +362,7 @@ __global__ void __launch_bounds__(kBlock, SMALL ? SRT_WAVES_PER_SIMD : SRT_WAVES
             tl_trips++;
 #endif
             rendezvous(ln, phase, fork, deliver, lane);
-            if (share_open_children(ln, phase, frames, fork, open, deliver, my_pair, ra, lane)) phase = LANE_TRACE;
+            if (share_open_children(ln, phase, frames, fork, open, deliver, my_pair, ra, lane, handed)) phase = LANE_TRACE;
             const unsigned long long m_trace = __ballot(phase == LANE_TRACE || phase == LANE_RETURN), m_light = __ballot(phase == LANE_LIGHT);
             if ((m_trace | m_light) == 0ull) {
                 if (__ballot(phase == LANE_WAIT) == 0ull) break;
@@ -528,6 +428,7 @@ __global__ void __launch_bounds__(kBlock, SMALL ? SRT_WAVES_PER_SIMD : SRT_WAVES
             atomicAdd(&stats[6], c3);
             for (int i = 0; i < 4; i++) atomicAdd(&stats[7 + i], (unsigned long long)sect[i]);
             for (int i = 0; i < PROF_SLOTS; i++) atomicAdd(&stats[16 + i], prof.cyc[i]);
+            atomicAdd(&stats[16 + 15], (unsigned long long)handed);   // a count, not cycles
             // the tail of the launch: how long wavefronts kept running after the counter ran out (100 MHz ticks)
             const unsigned long long tail = t_exit - t_dry;
             atomicMax(&stats[16 + 11], tail);
@@ -561,7 +462,7 @@ constexpr int kWalkVote = 16, kWalkRounds = 1 << 24, kWalkSteps = 2;
 template <bool EXACT, bool COUNT>
 __global__ void __launch_bounds__(kBlock, SRT_WAVES_PER_SIMD_MESH) mesh_trace_kernel(SceneView sc, RenderArgs ra, f3* __restrict__ samples,
                                                             unsigned long long* __restrict__ stats, uint32_t* __restrict__ work_counter,
-                                                            float4* __restrict__ mail, int walk_vote, int rounds, int steps, uint32_t chunk, uint32_t guide)
+                                                            float4* __restrict__ mail /* -DSRT_TIMELINE builds only */, int walk_vote, int rounds, int steps, uint32_t chunk, uint32_t guide, int share)
 {
     __shared__ uint32_t lds_stack[kWaves * STACK_DEPTH * 64];
     __shared__ uint32_t lds_pair[kWaves * 64];   // handing over subtrees: giver lane by rank
@@ -591,19 +492,35 @@ __global__ void __launch_bounds__(kBlock, SRT_WAVES_PER_SIMD_MESH) mesh_trace_ke
     int phase = MESH_IDLE;
     TreeFork fork;
     fork.given = 0u; fork.wait = 0u;
-    int32_t deliver = -1;      // >= 0: this lane traces a subtree for lane (deliver & 63), child (deliver >> 8) of its fork frame
-    float4* my_mail = mail ? mail + ((size_t)blockIdx.x * kWaves + wave) * kMailPerWave : nullptr;
+    int32_t deliver = -1;      // >= 0: this lane walks a subtree for lane (deliver & 63); deliver >> 8 is the giver's bit for it
+    uint32_t open = 0u;        // children this lane could give away (bit 2*level + child - 1); kept once `sharing` is on
+    bool sharing = false;      // wave-uniform: no new items, lanes share their trees
     uint32_t* my_pair = &lds_pair[wave * 64];
-    uint32_t trip = 0u;
+    uint32_t handed = 0u;
 
     uint32_t sect[4] = {0u, 0u, 0u, 0u};
     typename std::conditional<COUNT, ClockProf, NoProf>::type prof;
     uint32_t next = 0u, end = 0u, draw = chunk;
     bool dry = false;
 
-    // the lane's next state after a per-lane function returned LANE_*; `ret` is the sample's colour for LANE_IDLE
-    auto enter = [&](int lane_phase, f3 ret) {
-        if (lane_phase == LANE_IDLE) { deliver_colour(ln, ret, deliver, my_mail, samples); phase = MESH_IDLE; }
+    // the lane's next state after a per-lane function returned LANE_*; `ret` is the sample's colour for LANE_IDLE;
+    // up: the function was lane_return (frames may have gone, a later child may have started), else a frame may have
+    // been pushed
+    auto enter = [&](int lane_phase, f3 ret, bool up) {
+        if (sharing) {
+            if (up) {
+                open &= ln.level < 16 ? (1u << (2 * ln.level)) - 1u : 0xFFFFFFFFu;
+                if (lane_phase == LANE_TRACE && ln.level - 1 < kForkLevels) open &= ~(1u << (2 * (ln.level - 1) + (int32_t)((ln.key.node & 3u) - 1u) - 1));
+            } else if (lane_phase == LANE_TRACE && ln.level >= 1 && ln.level - 1 < kForkLevels && ln.depth >= kForkMinDepth) {
+                const float metal = sc.materials[2u * ln.mat].w;
+                if (metal != 0.0f) open |= 1u << (2 * (ln.level - 1));
+                if (metal != 1.0f) open |= 2u << (2 * (ln.level - 1));
+            }
+        }
+        if (lane_phase == LANE_IDLE) {
+            if (deliver >= 0) { ln.former = ret; phase = LANE_DELIVER; }
+            else { samples[ln.slot] = ret; phase = MESH_IDLE; }
+        }
         else if (lane_phase == LANE_WAIT) phase = MESH_WAIT;
         else if (lane_phase == LANE_RETURN) phase = MESH_RETURN;
         else if (lane_phase == LANE_TRACE) { tr.d = ln.qd; tr.cur = TRAV_NEW; phase = MESH_CLOSEST; }
@@ -623,23 +540,21 @@ __global__ void __launch_bounds__(kBlock, SRT_WAVES_PER_SIMD_MESH) mesh_trace_ke
 #ifdef SRT_TIMELINE
         if (dry) tl_trips++; else tl_trips += 1ull << 32;
 #endif
-        poll_mailbox(ln, phase, fork, my_mail, lane);
-        trip++;
-        if (my_mail != nullptr && dry && (trip % (uint32_t)kForkEvery) == 0u && (uint32_t)ra.mode == MODE_COLOR) {
-            uint32_t handed = 0u;
-            if (share_subtrees(ln, phase, frames, fork, deliver, my_mail, my_pair, sc, ra, lane, handed)) {
+        if (share != 0 && dry) {
+            if (!sharing) { open = open_children(ln, phase, frames, sc); sharing = true; }
+            rendezvous(ln, phase, fork, deliver, lane);
+            if (share_open_children(ln, phase, frames, fork, open, deliver, my_pair, ra, lane, handed)) {
                 tr.d = ln.qd; tr.cur = TRAV_NEW; phase = MESH_CLOSEST;
             }
-            if constexpr (COUNT) { if (lane == 0u) prof.cyc[15] += handed; }   // a count, not cycles
         }
         const bool walking = (phase == MESH_CLOSEST || phase == MESH_SHADOW) && tr.cur != TRAV_NONE;
         const int n_walk = __popcll(__ballot(walking));
         const int n_closest = __popcll(__ballot(phase == MESH_CLOSEST && !walking));
         const int n_shadow = __popcll(__ballot(phase == MESH_SHADOW && !walking));
         const int n_up = __popcll(__ballot(phase == MESH_RETURN || (phase == MESH_IDLE && !dry)));
-        const int n_wait = __popcll(__ballot(phase == MESH_WAIT));
+        const int n_wait = __popcll(__ballot(phase == MESH_WAIT || phase == LANE_DELIVER));
         if (n_walk + n_closest + n_shadow + n_up + n_wait == 0) break;
-        if (n_walk + n_closest + n_shadow + n_up == 0) continue;     // only lanes waiting for a colour that is about to land
+        if (n_walk + n_closest + n_shadow + n_up == 0) continue;     // givers and helpers that meet at the top of the loop
 
         if (n_walk >= walk_vote || (n_walk >= n_closest && n_walk >= n_shadow && n_walk >= n_up)) {
             // ---- a quantum of traversal
@@ -658,7 +573,7 @@ __global__ void __launch_bounds__(kBlock, SRT_WAVES_PER_SIMD_MESH) mesh_trace_ke
             if (phase == MESH_RETURN) {
                 f3 ret;
                 int p = lane_return(ln, ret, sc, ra, frames, fork);
-                enter(p, ret);
+                enter(p, ret, true);
             }
             prof.mark(PROF_RETURN);
             unsigned long long idle = __ballot(phase == MESH_IDLE);
@@ -694,7 +609,7 @@ __global__ void __launch_bounds__(kBlock, SRT_WAVES_PER_SIMD_MESH) mesh_trace_ke
             if (phase == MESH_CLOSEST && !walking) {
                 f3 ret;
                 int p = lane_on_closest(ln, tr.best, ret, sc, ra, frames, unit);
-                enter(p, ret);
+                enter(p, ret, false);
             }
             prof.mark(PROF_ON_CLOSEST);
         } else {
@@ -712,7 +627,7 @@ __global__ void __launch_bounds__(kBlock, SRT_WAVES_PER_SIMD_MESH) mesh_trace_ke
                 } else {
                     f3 ret;
                     int p = lane_shade(ln, ln.former, ret, sc, ra, frames, aux, unit);
-                    enter(p, ret);
+                    enter(p, ret, false);
                 }
             }
             prof.mark(PROF_LIGHT_EVAL);
@@ -740,6 +655,7 @@ __global__ void __launch_bounds__(kBlock, SRT_WAVES_PER_SIMD_MESH) mesh_trace_ke
             atomicAdd(&stats[6], c3);
             for (int i = 0; i < 4; i++) atomicAdd(&stats[7 + i], (unsigned long long)sect[i]);
             for (int i = 0; i < PROF_SLOTS; i++) atomicAdd(&stats[16 + i], prof.cyc[i]);
+            atomicAdd(&stats[16 + 15], (unsigned long long)handed);   // a count, not cycles
         }
     }
 }
@@ -848,17 +764,17 @@ hipError_t launch_trace(const SceneView& sc, const RenderArgs& ra_in, bool exact
     static const int walk_rounds = std::getenv("SRT_WALK_ROUNDS") ? std::atoi(std::getenv("SRT_WALK_ROUNDS")) : kWalkRounds;
     static const int walk_steps = std::getenv("SRT_WALK_STEPS") ? std::atoi(std::getenv("SRT_WALK_STEPS")) : kWalkSteps;
     static const bool allow_fork = !std::getenv("SRT_NO_SUBTREE_SHARING");
-    float4* mailboxes = allow_fork ? reinterpret_cast<float4*>(d_mail) : nullptr;
+    float4* mailboxes = reinterpret_cast<float4*>(d_mail);
+    const int share = allow_fork && (uint32_t)ra.mode == MODE_COLOR ? 1 : 0;   // lanes share the last ray trees of a launch
     if (!stackless) {
         static const uint32_t mesh_scatter = std::getenv("SRT_MESH_SCATTER_SAMPLES") ? (uint32_t)std::atoi(std::getenv("SRT_MESH_SCATTER_SAMPLES")) : 0u;
         set_item_order(ra, mesh_scatter);
-#define SRT_LAUNCH_MESH(E, C) hipLaunchKernelGGL((mesh_trace_kernel<E, C>), grid, block, 0, stream, sc, ra, s, d_stats, d_work_counter, mailboxes, walk_vote, walk_rounds, walk_steps, chunk, guide)
+#define SRT_LAUNCH_MESH(E, C) hipLaunchKernelGGL((mesh_trace_kernel<E, C>), grid, block, 0, stream, sc, ra, s, d_stats, d_work_counter, mailboxes, walk_vote, walk_rounds, walk_steps, chunk, guide, share)
         if (exact) { if (counted) SRT_LAUNCH_MESH(true, true); else SRT_LAUNCH_MESH(true, false); }
         else { if (counted) SRT_LAUNCH_MESH(false, true); else SRT_LAUNCH_MESH(false, false); }
 #undef SRT_LAUNCH_MESH
         return hipGetLastError();
     }
-    const int share = allow_fork && (uint32_t)ra.mode == MODE_COLOR ? 1 : 0;
     // The last samples of the pass in scattered order (with a stride that spreads the 64 lanes of a draw over the whole
     // picture): measured on the default scene at 1080p, a sample costs 0.89 ms in block order and 1.08 ms scattered, but
     // a launch that ends in block order runs 1.8 ms longer than its samples take.

@@ -85,6 +85,16 @@ def default_spec(with_rect=False):
     return s
 
 
+def glossy_spec():
+    """The default scene with smooth, half-metallic materials: every hit keeps the full recursion depth and starts all
+    three children (diffuse, metal, reflect), so a sample's ray tree is as deep and as wide as it can get."""
+    s = default_spec()
+    z = (0, 0, 0)
+    s.materials = [((0.78, 0.79, 0.33), 0.5, 0.995, z), ((1.0, 0.65, 0.62), 0.5, 0.65, z), ((0.5, 0.425, 0.15), 0.25, 0.7, z),
+                   (z, 0, 0.0, (50.0, 0.5, 0.5)), (z, 0, 0.0, (0.5, 0.5, 50.0)), ((1.0, 0.5, 0.5), 0.75, 0.85, z)]
+    return s
+
+
 # -- procedural meshes ---------------------------------------------------------------------------
 def uv_sphere(center, radius, n_lat, n_lon):
     """Triangle soup of a latitude/longitude sphere with outward vertex normals -> (pos9, nrm9)."""

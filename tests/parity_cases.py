@@ -42,6 +42,10 @@ CASES = [
     ("mesh-reflection-mode-bvhnode", lambda: helpers.mesh_spec(n=8), 96, 54, 1, 8, REFLECTION, BVH, 2),
     ("mesh-depth-mode-list", lambda: helpers.mesh_spec(n=10, with_rect=True), 96, 54, 1, 4, DEPTH, LIST, 1),
     ("mesh-only-tris", lambda: helpers.mesh_spec(n=8, with_spheres=False), 96, 54, 1, 4, COLOR, BVH, 2),
+    # deep and wide ray trees: more pending levels than the kernels' tree sharing covers (8), three children per node
+    ("default-depth12", helpers.default_spec, 48, 27, 2, 12, COLOR, BVH, 7),
+    ("glossy-depth7-three-children", helpers.glossy_spec, 40, 24, 1, 7, COLOR, BVH, 3),
+    ("glossy-depth6-list", helpers.glossy_spec, 48, 27, 2, 6, COLOR, LIST, 11),
 ]
 
 

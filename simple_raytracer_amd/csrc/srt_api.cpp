@@ -137,7 +137,15 @@ int launch(srt_ctx* c, const srt_render_params* p, uint32_t* d_out, size_t capac
     SRT_HIP(c, hipSetDevice(c->device));
     // Samples per pass: as many as fit the sample buffer budget (12 bytes per pixel and sample) and the
     // 2^31 work-item limit of one launch.
-    if (ra.n_work == 0u) return SRT_OK;
+    if (ra.n_work == 0u) {
+        // a rank without tiles: nothing to launch, and the counters of the "render" are all zero
+        c->stats.rays_path = c->stats.rays_shadow = c->stats.hit_nodes = 0;
+        c->stats.box_tests = c->stats.sphere_tests = c->stats.tri_tests = c->stats.rect_tests = 0;
+        c->stats.trace_sections = c->stats.trace_lanes = c->stats.light_sections = c->stats.light_lanes = 0;
+        for (int i = 0; i < 16; i++) c->stats.section_cycles[i] = 0;
+        c->stats.kernel_ms = 0.0f;
+        return SRT_OK;
+    }
     uint64_t per_sample = (uint64_t)ra.n_work * 12u;
     uint64_t fit = c->sample_budget / per_sample;
     uint64_t by_items = (((uint64_t)1 << 31) - 1) / ra.n_work;

@@ -316,3 +316,15 @@ def test_gpu_subtree_sharing_keeps_the_image(gpu, oracle):
         assert st[k] == ost[k], k
     assert st["rays_path"] > 8 * w * h           # the trees are deep (1.5 rays per pixel on the plain mesh scene)
     assert st["section_cycles"][15] > 0          # subtrees were handed over
+
+
+def test_gpu_random_render_parameters_match_kernel_source_on_cpu(gpu, emu_lib):
+    """Random sizes (down to 1x1), samples, depths (0..16), seeds, clamps, world kinds and tile layouts -- including
+    ranks that own no tile at all -- on the GPU and through the CPU harness of the same kernel source: identical
+    pictures and ray counts.  (The CPU harness itself is checked against the oracle in test_kernel_logic_cpu.py.)"""
+    import os
+    import sys
+    sys.path.insert(0, os.path.join(helpers.ROOT, "tools"))
+    import gpu_fuzz
+    emu = srt.Renderer(library=emu_lib, strict=False)
+    assert gpu_fuzz.run(gpu, emu, 60, 2024) == []

@@ -95,6 +95,14 @@ def glossy_spec():
     return s
 
 
+def many_materials_spec():
+    """The glossy scene with 80 unused materials on top: more than the kernels for small scenes keep in LDS, so the
+    general stackless kernel renders it."""
+    s = glossy_spec()
+    s.materials = s.materials + [((0.1 * (i % 7), 0.2, 0.3), 0.5, 0.5, (0, 0, 0)) for i in range(80)]
+    return s
+
+
 # -- procedural meshes ---------------------------------------------------------------------------
 def uv_sphere(center, radius, n_lat, n_lon):
     """Triangle soup of a latitude/longitude sphere with outward vertex normals -> (pos9, nrm9)."""

@@ -46,6 +46,8 @@ CASES = [
     ("default-depth12", helpers.default_spec, 48, 27, 2, 12, COLOR, BVH, 7),
     ("glossy-depth7-three-children", helpers.glossy_spec, 40, 24, 1, 7, COLOR, BVH, 3),
     ("glossy-depth6-list", helpers.glossy_spec, 48, 27, 2, 6, COLOR, LIST, 11),
+    ("many-materials-bvhnode", helpers.many_materials_spec, 96, 54, 2, 5, COLOR, BVH, 4),
+    ("many-materials-list", helpers.many_materials_spec, 96, 54, 2, 5, COLOR, LIST, 4),
 ]
 
 

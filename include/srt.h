@@ -182,6 +182,18 @@ int  srt_render_progressive(srt_ctx* ctx, const srt_render_params* p, uint32_t* 
 int  srt_progress(srt_ctx* ctx, int* passes_done, int* passes_total);
 int  srt_read_preview(srt_ctx* ctx, uint32_t* rgba_out);
 
+/* The post-process filters of the finished picture: Sorting.BlurArray (MiscFunctions.cs:124-191), Sorting.ContrastBlurArray
+ * (:193-335) and Sorting.Despeckle (:337-416), which Game1.Update runs blurPasses times on buffer1Data once the render is
+ * done (Game1.cs:226-232).  `array` is the caller's row-major width x height picture in the packing of srt_render
+ * (MonoGame Color); it is filtered in place, `passes` times (>= 1), with the reference's in-place semantics: a pixel sees
+ * the new values of its left neighbour and of the row above.  Only interior pixels change.  `weight` is clamped to
+ * [0, 1] as the reference does; `contrast` / `threshold` are in byte units (0..255) of 0.3 R + 0.6 G + 0.11 B.
+ * Blocking; not allowed while an asynchronous render is in flight. */
+enum { SRT_POST_BLUR = 0, SRT_POST_CONTRAST_BLUR = 1, SRT_POST_DESPECKLE = 2 };
+int  srt_blur_array(srt_ctx* ctx, uint32_t* array, int32_t width, int32_t height, float weight, int32_t passes);
+int  srt_contrast_blur_array(srt_ctx* ctx, uint32_t* array, int32_t width, int32_t height, float weight, float contrast, int32_t passes);
+int  srt_despeckle(srt_ctx* ctx, uint32_t* array, int32_t width, int32_t height, float weight, float threshold, int32_t passes);
+
 /* Counters of the renders since the previous collection (a blocking render collects, so after srt_render
  * these are that render's counters).  Waits for the most recent launch. */
 int  srt_get_stats(srt_ctx* ctx, srt_stats* out);

@@ -100,6 +100,11 @@ def lib():
         L.orc_get_ray_color.argtypes = [C.c_void_p, C.c_int, F3, F3, C.c_int, C.c_float] + [C.c_uint32] * 3 + [F3]
         L.orc_get_debug_color.argtypes = [C.c_void_p, C.c_int, C.c_int, F3, F3, C.c_int] + [C.c_uint32] * 3 + [F3]
         L.orc_get_debug_color.restype = None
+        L.orc_blur_array.argtypes = [C.c_void_p, C.c_int32, C.c_int32, C.c_float]
+        L.orc_contrast_blur_array.argtypes = [C.c_void_p, C.c_int32, C.c_int32, C.c_float, C.c_float]
+        L.orc_despeckle.argtypes = [C.c_void_p, C.c_int32, C.c_int32, C.c_float, C.c_float]
+        for name in ("orc_blur_array", "orc_contrast_blur_array", "orc_despeckle"):
+            getattr(L, name).restype = None
         _lib = L
     return _lib
 
@@ -225,3 +230,24 @@ def default_camera(width=1280, height=720):
 def rgba_to_rgb8(img):
     """(H, W) uint32 R|G<<8|B<<16|A<<24 -> (H, W, 3) uint8."""
     return np.stack([(img >> s) & 0xFF for s in (0, 8, 16)], axis=-1).astype(np.uint8)
+
+
+# -- Sorting.* (MiscFunctions.cs:122-416): one in-place pass each; `array` is a (height, width) uint32 image -------
+def _post(fn, array, *args):
+    import numpy as np
+    a = np.ascontiguousarray(array, dtype=np.uint32).copy()
+    h, w = a.shape
+    fn(a.ctypes.data_as(C.c_void_p), w, h, *args)
+    return a
+
+
+def BlurArray(array, weight):
+    return _post(lib().orc_blur_array, array, C.c_float(weight))
+
+
+def ContrastBlurArray(array, weight, contrast):
+    return _post(lib().orc_contrast_blur_array, array, C.c_float(weight), C.c_float(contrast))
+
+
+def Despeckle(array, weight, threshold):
+    return _post(lib().orc_despeckle, array, C.c_float(weight), C.c_float(threshold))

@@ -881,9 +881,109 @@ void renderBlock(const orc_scene* s, const Surface* world, const orc_camera* cam
 
 }  // namespace
 
+// ---------------------------------------------------------------------------------------
+// Sorting.BlurArray / ContrastBlurArray / Despeckle (MiscFunctions.cs:122-416): the post-process filters that
+// Game1.Update runs on the finished Color[] (Game1.cs:226-232 calls Despeckle blurPasses times).  They work IN PLACE
+// in row-major order (`Color[] originalArray = array` is an alias, not a copy), so a pixel sees the new values of its
+// left neighbour and of the row above and the old values of the rest.  Only interior pixels are touched.
+// ---------------------------------------------------------------------------------------
+inline Vec ColorToBytes(uint32_t c) { return V((float)(c & 255u), (float)((c >> 8) & 255u), (float)((c >> 16) & 255u)); }   // .R .G .B as float
+inline bool VecDiffers(Vec a, Vec b) { return a.X != b.X || a.Y != b.Y || a.Z != b.Z; }                                      // Vector3 operator !=
+inline float Mixdown(Vec c) { return c.X * 0.3f + c.Y * 0.6f + c.Z * 0.11f; }                                                // :231, :364
+
+struct Neighbours { Vec left, right, up, down, leftUp, rightUp, leftDown, rightDown; };
+inline Neighbours ReadNeighbours(const uint32_t* array, int x, int y, int width)
+{
+    Neighbours n;
+    n.left = ColorToBytes(array[x - 1 + (y * width)]);
+    n.right = ColorToBytes(array[x + 1 + (y * width)]);
+    n.up = ColorToBytes(array[x + ((y - 1) * width)]);
+    n.down = ColorToBytes(array[x + ((y + 1) * width)]);
+    n.leftUp = ColorToBytes(array[x - 1 + ((y - 1) * width)]);
+    n.leftDown = ColorToBytes(array[x - 1 + ((y + 1) * width)]);
+    n.rightUp = ColorToBytes(array[x + 1 + ((y - 1) * width)]);
+    n.rightDown = ColorToBytes(array[x + 1 + ((y + 1) * width)]);
+    return n;
+}
+// (tempColorLeft + tempColorRight + tempColorUp + tempColorDown + tempColorLeftUp + tempColorLeftDown + tempColorRightUp + tempColorRightDown) / 8
+inline Vec MeanOfEight(const Neighbours& n) { return (n.left + n.right + n.up + n.down + n.leftUp + n.leftDown + n.rightUp + n.rightDown) / 8; }
+// new Color(v.X / 255, v.Y / 255, v.Z / 255): scalar float / int is a true division
+inline uint32_t ColorFromBytes(Vec v) { return PackColor(v.X / 255, v.Y / 255, v.Z / 255); }
+
+void BlurArray(uint32_t* array, int width, int height, float weight)   // MiscFunctions.cs:124-191
+{
+    for (int y = 0; y < height; y++)
+        for (int x = 0; x < width; x++)
+            if (y > 0 && y < height - 1 && x > 0 && x < width - 1) {
+                weight = ClampF(weight, 0, 1);
+                Vec originalColor = ColorToBytes(array[x + (y * width)]);
+                Neighbours n = ReadNeighbours(array, x, y, width);
+                Vec newVectorColor = (originalColor * (1 - weight)) + (MeanOfEight(n) * weight);
+                array[x + (y * width)] = ColorFromBytes(newVectorColor);
+            }
+}
+
+void ContrastBlurArray(uint32_t* array, int width, int height, float weight, float contrast)   // MiscFunctions.cs:193-335
+{
+    for (int y = 0; y < height; y++)
+        for (int x = 0; x < width; x++)
+            if (y > 0 && y < height - 1 && x > 0 && x < width - 1) {
+                weight = ClampF(weight, 0, 1);
+                Vec originalColor = ColorToBytes(array[x + (y * width)]);
+                float grayscaleOriginal = Mixdown(originalColor);
+                Neighbours n = ReadNeighbours(array, x, y, width);
+                // identities in the order they are added (:239-288)
+                const Vec identities[8] = {n.left, n.right, n.up, n.down, n.leftUp, n.leftDown, n.rightUp, n.rightDown};
+                Vec colorsToBlur[8];
+                int count = 0;
+                for (const Vec& original : identities) {
+                    float grayscale = Mixdown(original);
+                    if (grayscaleOriginal >= grayscale) {
+                        if (std::fabs(grayscaleOriginal - grayscale) > contrast) colorsToBlur[count++] = original;
+                    } else {
+                        if (std::fabs(grayscale - grayscaleOriginal) > contrast) colorsToBlur[count++] = original;
+                    }
+                }
+                Vec blurColor;
+                if (count != 0) {
+                    blurColor = colorsToBlur[0];
+                    for (int i = 0; i < count; i++)
+                        if (VecDiffers(colorsToBlur[i], colorsToBlur[0])) {
+                            blurColor = blurColor / 2;
+                            blurColor = blurColor + colorsToBlur[i] / 2;
+                        }
+                } else
+                    blurColor = originalColor;
+                Vec newVectorColor = (originalColor * (1 - weight)) + (blurColor * weight);
+                array[x + (y * width)] = ColorFromBytes(newVectorColor);
+            }
+}
+
+void Despeckle(uint32_t* array, int width, int height, float weight, float threshold)   // MiscFunctions.cs:337-416
+{
+    for (int y = 0; y < height; y++)
+        for (int x = 0; x < width; x++)
+            if (y > 0 && y < height - 1 && x > 0 && x < width - 1) {
+                weight = ClampF(weight, 0, 1);
+                Vec originalColor = ColorToBytes(array[x + (y * width)]);
+                float grayscaleOriginal = Mixdown(originalColor);
+                Neighbours n = ReadNeighbours(array, x, y, width);
+                if (grayscaleOriginal <= 0 || grayscaleOriginal > threshold) {
+                    Vec blurColor = (originalColor * (1 - weight)) + (MeanOfEight(n) * weight);
+                    Vec newVectorColor = (originalColor * (1 - weight)) + (blurColor * weight);
+                    array[x + (y * width)] = ColorFromBytes(newVectorColor);
+                }
+            }
+}
+
+
 extern "C" {
 
 const char* orc_last_error(void) { return g_error.c_str(); }
+
+void orc_blur_array(uint32_t* array, int32_t width, int32_t height, float weight) { BlurArray(array, width, height, weight); }
+void orc_contrast_blur_array(uint32_t* array, int32_t width, int32_t height, float weight, float contrast) { ContrastBlurArray(array, width, height, weight, contrast); }
+void orc_despeckle(uint32_t* array, int32_t width, int32_t height, float weight, float threshold) { Despeckle(array, width, height, weight, threshold); }
 
 orc_scene* orc_scene_create(const orc_material* mats, int32_t n_mats, const orc_tri* tris, int32_t n_tris,
                             const orc_sphere* spheres, int32_t n_spheres, const orc_rect* rects, int32_t n_rects,

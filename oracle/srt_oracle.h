@@ -90,6 +90,11 @@ int orc_aabb_hit(const float bmin[3], const float bmax[3], const float o[3], con
 void orc_sky(const float d[3], float rgb[3]);
 int  orc_depth_heuristic(int depth, float smoothness);
 uint32_t orc_pack_color(float r, float g, float b);
+/* Sorting.BlurArray / ContrastBlurArray / Despeckle (MiscFunctions.cs:124, :193, :337): one in-place pass over a
+ * row-major packed Color array (R | G<<8 | B<<16 | A<<24). */
+void orc_blur_array(uint32_t* array, int32_t width, int32_t height, float weight);
+void orc_contrast_blur_array(uint32_t* array, int32_t width, int32_t height, float weight, float contrast);
+void orc_despeckle(uint32_t* array, int32_t width, int32_t height, float weight, float threshold);
 void orc_rng_words(uint32_t seed, uint32_t pixel, uint32_t sample, uint32_t node, uint32_t call, uint32_t out[4]);
 /* Random.Next(lo, lo + range) as the next base-`range` digit of *word (which is advanced). */
 int  orc_rng_next(uint32_t* word, int lo, int range);

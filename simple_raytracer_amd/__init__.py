@@ -9,7 +9,8 @@ from ._native import (LAYOUT_FRAME, LAYOUT_TILES, MODE_COLOR, MODE_DEPTH, MODE_D
 from .raytracing import (Camera, Light, LightList, Material, PointLight, RectAxis, Sphere, Surface, SurfaceList, Tri, TriMesh,
                          Vert)
 from .renderer import Renderer, rgba_to_rgb8
+from .sorting import Sorting
 
-__all__ = ["Camera", "Light", "LightList", "Material", "PointLight", "RectAxis", "Sphere", "Surface", "SurfaceList", "Tri",
+__all__ = ["Sorting", "Camera", "Light", "LightList", "Material", "PointLight", "RectAxis", "Sphere", "Surface", "SurfaceList", "Tri",
            "TriMesh", "Vert", "Renderer", "rgba_to_rgb8", "SrtError", "WORLD_BVHNODE", "WORLD_SURFACELIST", "MODE_COLOR",
            "MODE_NORMAL", "MODE_DEPTH", "MODE_LIGHTS", "MODE_DIFFUSE", "MODE_REFLECTION", "LAYOUT_FRAME", "LAYOUT_TILES"]

@@ -496,3 +496,49 @@ int srt_assemble_tiles(srt_ctx* c, const srt_render_params* p, const void* d_gat
 }
 
 }  // extern "C"
+
+namespace {
+
+int post_filter(srt_ctx* c, int filter, uint32_t* array, int32_t width, int32_t height, float weight, float param, int32_t passes)
+{
+    if (!c) return SRT_E_INVALID;
+    if (!array) return fail(c, SRT_E_INVALID, "array is NULL");
+    if (width < 1 || height < 1) return fail(c, SRT_E_INVALID, "width and height must be positive");
+    if (passes < 1) return fail(c, SRT_E_INVALID, "passes must be at least 1");
+    if ((int64_t)width * (int64_t)height > ((int64_t)1 << 31) - 1) return fail(c, SRT_E_LIMIT, "more than 2^31 pixels");
+    if (c->async_pending) return fail(c, SRT_E_STATE, "an asynchronous render is in flight");
+    SRT_HIP(c, hipSetDevice(c->device));
+    const size_t bytes = (size_t)width * (size_t)height * sizeof(uint32_t);
+    uint32_t* d[2] = {nullptr, nullptr};
+    hipError_t e = hipMalloc((void**)&d[0], bytes);
+    if (e == hipSuccess) e = hipMalloc((void**)&d[1], bytes);
+    if (e == hipSuccess) e = hipMemcpyAsync(d[0], array, bytes, hipMemcpyHostToDevice, c->stream);
+    int from = 0;
+    for (int32_t i = 0; i < passes && e == hipSuccess; i++, from ^= 1)
+        e = launch_post_filter(filter, d[from], d[from ^ 1], width, height, weight, param, c->stream);
+    if (e == hipSuccess) e = hipMemcpyAsync(array, d[from], bytes, hipMemcpyDeviceToHost, c->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+    if (d[0]) (void)hipFree(d[0]);
+    if (d[1]) (void)hipFree(d[1]);
+    if (e != hipSuccess) return hip_fail(c, e, "post-process filter");
+    return SRT_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int srt_blur_array(srt_ctx* ctx, uint32_t* array, int32_t width, int32_t height, float weight, int32_t passes)
+{
+    return post_filter(ctx, SRT_POST_BLUR, array, width, height, weight, 0.0f, passes);
+}
+int srt_contrast_blur_array(srt_ctx* ctx, uint32_t* array, int32_t width, int32_t height, float weight, float contrast, int32_t passes)
+{
+    return post_filter(ctx, SRT_POST_CONTRAST_BLUR, array, width, height, weight, contrast, passes);
+}
+int srt_despeckle(srt_ctx* ctx, uint32_t* array, int32_t width, int32_t height, float weight, float threshold, int32_t passes)
+{
+    return post_filter(ctx, SRT_POST_DESPECKLE, array, width, height, weight, threshold, passes);
+}
+
+}  // extern "C"

@@ -22,6 +22,9 @@ size_t trace_timeline_offset();   // experiments: where a -DSRT_TIMELINE build l
 // preview (running sum times preview_scale) to d_out as well.
 hipError_t launch_resolve(const RenderArgs& ra, const float* d_samples, float* d_running, uint32_t* d_out, bool first_pass, bool last_pass,
                           float preview_scale, hipStream_t stream);
+// One in-place pass of a post-process filter (SRT_POST_*): d_in is the picture before the pass and stays untouched,
+// d_out receives the picture after it.  weight is clamped here; param = contrast / threshold.
+hipError_t launch_post_filter(int filter, const uint32_t* d_in, uint32_t* d_out, int width, int height, float weight, float param, hipStream_t stream);
 hipError_t launch_assemble(const RenderArgs& ra, const uint32_t* d_gathered, size_t stride, uint32_t* d_frame, hipStream_t stream);
 
 }  // namespace srt

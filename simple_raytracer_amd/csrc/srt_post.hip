@@ -1,0 +1,149 @@
+// srt_post.hip -- the post-process filters of the finished picture: Sorting.BlurArray, ContrastBlurArray and Despeckle
+// (MiscFunctions.cs:124-191, :193-335, :337-416; Game1.cs:226-232 runs Despeckle blurPasses times).
+//
+// The reference filters work IN PLACE in row-major order (`Color[] originalArray = array` is an alias, not a copy): the
+// new value of pixel (x, y) is computed from the NEW values of (x-1, y) and of row y-1 and from the OLD values of
+// (x+1, y) and of row y+1.  That is a recurrence, not a stencil; what it leaves free is the skewed order: all pixels
+// with the same x + 2y can be computed together, because everything (x, y) reads was finished at x + 2y - 1 at the
+// latest and everything that reads its old value comes later.
+//
+// post_band_kernel gives every interior row of a band (up to 1024 rows) one thread of a single workgroup.  At step t the
+// thread of local row r handles column 1 + t - 2r.  It keeps the old values it needs (its own row and the row below,
+// from the untouched input picture) in registers as a sliding window, its left neighbour's new value in a register,
+// and takes the three new values of the row above from a 4-deep ring in LDS that the thread above wrote one to three
+// steps earlier; one barrier per step.  The first row of a band reads the finished row above it from the output
+// picture, so bands run one after the other.  The output picture starts as a copy of the input, and a pixel is written
+// only when its value changes.
+//
+// It is a latency-bound kernel by construction (W + 2 * rows dependent steps on one compute unit): 8 bytes read and at
+// most 4 written per pixel, far from any roofline.  The arithmetic is the reference's, float for float: bytes to float,
+// the sum of the eight neighbours left to right in the order the source adds them, Vector3 / 8 as a multiplication by
+// 0.125, `new Color(v / 255)` as a true division followed by (int)(c * 255) with clamping.
+#include <hip/hip_runtime.h>
+
+#include "../../include/srt.h"
+#include "srt_launch.h"
+
+namespace srt {
+
+namespace {
+
+constexpr int kPostRows = 1024;   // rows per band = threads of the workgroup
+
+__device__ __forceinline__ f3 bytes_of(uint32_t c) { return mk3((float)(c & 255u), (float)((c >> 8) & 255u), (float)((c >> 16) & 255u)); }
+__device__ __forceinline__ uint32_t color_of(f3 v) { return pack_color(v.x / 255.0f, v.y / 255.0f, v.z / 255.0f); }
+__device__ __forceinline__ float mixdown(f3 c) { return c.x * 0.3f + c.y * 0.6f + c.z * 0.11f; }   // MiscFunctions.cs:231, :364
+__device__ __forceinline__ f3 lerp_to(f3 original, f3 other, float weight)   // (originalColor * (1 - weight)) + (other * weight)
+{
+    return add3(scale3(original, 1.0f - weight), scale3(other, weight));
+}
+
+struct Window { uint32_t left, right, up, down, left_up, right_up, left_down, right_down; };
+
+// tempColorLeft + tempColorRight + tempColorUp + tempColorDown + tempColorLeftUp + tempColorLeftDown + tempColorRightUp
+// + tempColorRightDown, then / 8 (MiscFunctions.cs:181, :402)
+__device__ __forceinline__ f3 mean_of_eight(const Window& w)
+{
+    f3 s = add3(bytes_of(w.left), bytes_of(w.right));
+    s = add3(s, bytes_of(w.up));
+    s = add3(s, bytes_of(w.down));
+    s = add3(s, bytes_of(w.left_up));
+    s = add3(s, bytes_of(w.left_down));
+    s = add3(s, bytes_of(w.right_up));
+    s = add3(s, bytes_of(w.right_down));
+    return scale3(s, 0.125f);
+}
+
+template <int FILTER>
+__device__ __forceinline__ uint32_t filtered(uint32_t current, const Window& w, float weight, float param)
+{
+    const f3 original = bytes_of(current);
+    if (FILTER == SRT_POST_BLUR) {
+        return color_of(lerp_to(original, mean_of_eight(w), weight));
+    } else if (FILTER == SRT_POST_DESPECKLE) {
+        const float gray = mixdown(original);
+        if (!(gray <= 0.0f || gray > param)) return current;                          // :399
+        const f3 blur = lerp_to(original, mean_of_eight(w), weight);                   // :401-402
+        return color_of(lerp_to(original, blur, weight));                              // :404-407
+    } else {
+        // ContrastBlurArray: the neighbours whose gray value differs from the pixel's by more than `contrast`, in the
+        // order the source collects them; starting from the first, every one that differs from the first is mixed in
+        // half and half (:290-322)
+        const float gray = mixdown(original);
+        const uint32_t order[8] = {w.left, w.right, w.up, w.down, w.left_up, w.left_down, w.right_up, w.right_down};
+        bool any = false;
+        f3 first = original, blur = original;
+        for (int i = 0; i < 8; i++) {
+            const f3 c = bytes_of(order[i]);
+            const float g = mixdown(c);
+            const float diff = gray >= g ? gray - g : g - gray;
+            if (!(__builtin_fabsf(diff) > param)) continue;
+            if (!any) { any = true; first = c; blur = c; }
+            else if (c.x != first.x || c.y != first.y || c.z != first.z) blur = add3(scale3(blur, 0.5f), scale3(c, 0.5f));
+        }
+        return color_of(lerp_to(original, blur, weight));
+    }
+}
+
+template <int FILTER>
+__global__ void __launch_bounds__(kPostRows) post_band_kernel(const uint32_t* __restrict__ in, uint32_t* out, int width, int height, int row0,
+                                                               int rows, float weight, float param)
+{
+    __shared__ uint32_t ring[kPostRows][4];   // new values of the last four columns of every row of the band
+    const int r = (int)threadIdx.x, y = row0 + r;
+    const bool mine = r < rows;
+    const uint32_t* own = in + (size_t)(mine ? y : row0) * (size_t)width;
+    const uint32_t* below = own + width;
+    const uint32_t* above_in = own - width;
+    const uint32_t* above_out = out + (size_t)(row0 - 1) * (size_t)width;   // finished before this band started
+    // the window of old values slides along with the thread's column
+    uint32_t cur = 0u, right = 0u, d_left = 0u, d_mid = 0u, d_right = 0u, left_new = 0u;
+    if (mine) { cur = own[1]; right = own[2]; d_left = below[0]; d_mid = below[1]; d_right = below[2]; left_new = own[0]; }
+    const int steps = (width - 2) + 2 * (rows - 1);
+    for (int t = 0; t < steps; t++) {
+        const int x = 1 + t - 2 * r;
+        if (mine && x >= 1 && x <= width - 2) {
+            Window w;
+            w.left = left_new; w.right = right;
+            w.down = d_mid; w.left_down = d_left; w.right_down = d_right;
+            if (r == 0) {
+                w.left_up = above_out[x - 1]; w.up = above_out[x]; w.right_up = above_out[x + 1];
+            } else {
+                // columns 0 and width - 1 are never filtered: their "new" value is the input's
+                w.left_up = x - 1 == 0 ? above_in[0] : ring[r - 1][(x - 1) & 3];
+                w.up = ring[r - 1][x & 3];
+                w.right_up = x + 1 == width - 1 ? above_in[width - 1] : ring[r - 1][(x + 1) & 3];
+            }
+            const uint32_t now = filtered<FILTER>(cur, w, weight, param);
+            if (now != cur) out[(size_t)y * (size_t)width + (size_t)x] = now;
+            ring[r][x & 3] = now;
+            left_new = now;
+            // slide: the loads are for the next step and have the barrier to arrive in
+            cur = right;
+            d_left = d_mid; d_mid = d_right;
+            if (x + 2 <= width - 1) { right = own[x + 2]; d_right = below[x + 2]; }
+        }
+        __syncthreads();
+    }
+}
+
+}  // namespace
+
+hipError_t launch_post_filter(int filter, const uint32_t* d_in, uint32_t* d_out, int width, int height, float weight, float param, hipStream_t stream)
+{
+    hipError_t e = hipMemcpyAsync(d_out, d_in, (size_t)width * (size_t)height * sizeof(uint32_t), hipMemcpyDeviceToDevice, stream);
+    if (e != hipSuccess) return e;
+    if (width < 3 || height < 3) return hipSuccess;   // no interior pixel
+    weight = weight < 0.0f ? 0.0f : (weight > 1.0f ? 1.0f : weight);   // Math.Clamp(weight, 0, 1)
+    for (int row0 = 1; row0 <= height - 2; row0 += kPostRows) {
+        const int rows = height - 1 - row0 < kPostRows ? height - 1 - row0 : kPostRows;
+        if (filter == SRT_POST_BLUR) hipLaunchKernelGGL((post_band_kernel<SRT_POST_BLUR>), dim3(1), dim3(kPostRows), 0, stream, d_in, d_out, width, height, row0, rows, weight, param);
+        else if (filter == SRT_POST_CONTRAST_BLUR) hipLaunchKernelGGL((post_band_kernel<SRT_POST_CONTRAST_BLUR>), dim3(1), dim3(kPostRows), 0, stream, d_in, d_out, width, height, row0, rows, weight, param);
+        else hipLaunchKernelGGL((post_band_kernel<SRT_POST_DESPECKLE>), dim3(1), dim3(kPostRows), 0, stream, d_in, d_out, width, height, row0, rows, weight, param);
+        e = hipGetLastError();
+        if (e != hipSuccess) return e;
+    }
+    return hipSuccess;
+}
+
+}  // namespace srt

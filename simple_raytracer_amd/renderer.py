@@ -122,6 +122,27 @@ class Renderer:
     def read_preview(self, out):
         self._check(self._lib.srt_read_preview(self._ctx, out.ctypes.data_as(C.c_void_p)))
 
+    # -- post-process filters of the finished picture (Sorting.*, MiscFunctions.cs:122-416) --------
+    def _post(self, fn, array, *args):
+        a = np.ascontiguousarray(array, dtype=np.uint32).copy()
+        if a.ndim != 2:
+            raise ValueError("array must be a (height, width) picture")
+        h, w = a.shape
+        self._check(fn(self._ctx, a.ctypes.data_as(C.c_void_p), w, h, *args))
+        return a
+
+    def blur_array(self, array, weight, passes=1):
+        """Sorting.BlurArray (MiscFunctions.cs:124), `passes` times, with its in-place semantics -> new picture."""
+        return self._post(self._lib.srt_blur_array, array, C.c_float(weight), int(passes))
+
+    def contrast_blur_array(self, array, weight, contrast, passes=1):
+        """Sorting.ContrastBlurArray (MiscFunctions.cs:193)."""
+        return self._post(self._lib.srt_contrast_blur_array, array, C.c_float(weight), C.c_float(contrast), int(passes))
+
+    def despeckle(self, array, weight, threshold, passes=1):
+        """Sorting.Despeckle (MiscFunctions.cs:337), what Game1.Update runs blurPasses times (Game1.cs:226-232)."""
+        return self._post(self._lib.srt_despeckle, array, C.c_float(weight), C.c_float(threshold), int(passes))
+
     def poll(self):
         done = C.c_int(0)
         self._check(self._lib.srt_poll(self._ctx, C.byref(done)))

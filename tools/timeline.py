@@ -15,7 +15,7 @@ from simple_raytracer_amd import game1  # noqa: E402
 path = os.environ["SRT_TIMELINE_FILE"]
 r = srt.Renderer(device=0)
 mesh = [a for a in sys.argv[1:] if a in ("c3", "c4", "c5")]
-depth = 8
+depth = int(os.environ.get("SRT_TL_DEPTH", "8"))
 if mesh:
     sys.path.insert(0, "tools")
     from big_scenes import CONFIGS

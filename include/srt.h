@@ -182,6 +182,14 @@ int  srt_render_progressive(srt_ctx* ctx, const srt_render_params* p, uint32_t* 
 int  srt_progress(srt_ctx* ctx, int* passes_done, int* passes_total);
 int  srt_read_preview(srt_ctx* ctx, uint32_t* rgba_out);
 
+/* The reference's second threading technique, `mixBufferTechnique` (Game1.cs:56, :174-175): Parallel.For(startThreadFull)
+ * gives each of n_buffers threads a Color[] of its own, renderBlockFull (:320-374) fills it with ONE sample per pixel --
+ * the colour still divided by p->samples (:352), then gamma and packing -- and Game1.Update mixes the buffers into
+ * buffer1Data one after the other in 8-bit colour: new Color(buffer1Data.ToVector3() / 2 + buffer.ToVector3() / 2)
+ * (:209-220), starting from default (zero) Colors.  Buffer b is traced with sample index b of the counter RNG (thread
+ * b's System.Random).  Blocking; SRT_LAYOUT_FRAME, world_size 1 and SRT_MODE_COLOR only. */
+int  srt_render_mix_buffers(srt_ctx* ctx, const srt_render_params* p, int32_t n_buffers, uint32_t* rgba_out);
+
 /* The post-process filters of the finished picture: Sorting.BlurArray (MiscFunctions.cs:124-191), Sorting.ContrastBlurArray
  * (:193-335) and Sorting.Despeckle (:337-416), which Game1.Update runs blurPasses times on buffer1Data once the render is
  * done (Game1.cs:226-232).  `array` is the caller's row-major width x height picture in the packing of srt_render

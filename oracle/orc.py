@@ -210,6 +210,24 @@ class Scene:
         return out, stats
 
 
+def _render_mix_buffers(self, cam, width, height, n_buffers, samples=500, max_depth=4, color_clamp=1.0, seed=1, world_kind=WORLD_BVHNODE,
+                        threads=0):
+    """The mix-buffer technique (Game1.cs:174-175, :209-220, :320-388) -> (picture, stats)."""
+    p = Params(width=width, height=height, samples=samples, max_depth=max_depth, color_clamp=color_clamp, seed=seed,
+               mode=MODE_COLOR, world_kind=world_kind, threads=threads, drop_remainder_rows=0)
+    out = np.zeros((height, width), dtype=np.uint32)
+    st = Stats()
+    L = lib()
+    L.orc_render_mix_buffers.argtypes = [C.c_void_p, C.POINTER(Camera), C.POINTER(Params), C.c_int32, C.c_void_p, C.POINTER(Stats)]
+    rc = L.orc_render_mix_buffers(self._h, C.byref(cam), C.byref(p), n_buffers, out.ctypes.data_as(C.c_void_p), C.byref(st))
+    if rc != 0:
+        raise RuntimeError("oracle: %s (rc=%d)" % (L.orc_last_error().decode(), rc))
+    return out, {k: getattr(st, k) for k, _ in Stats._fields_}
+
+
+Scene.render_mix_buffers = _render_mix_buffers
+
+
 def default_scene():
     """The literals of Game1.Initialize (Game1.cs:96-144): camera, 6 materials, 5 spheres, 2 lights."""
     mats = [material((0.78, 0.79, 0.33), 0.0, 0.995), material((1.0, 0.65, 0.62), 1.0, 0.65), material((0.5, 0.425, 0.15), 0.0, 0.45),

@@ -837,8 +837,10 @@ Vec A3(const float* p) { return V(p[0], p[1], p[2]); }
 
 // Game1.cs:264-317, one band of scanlines.
 void renderBlock(const orc_scene* s, const Surface* world, const orc_camera* cam, const orc_params* p, int yStart, int yEnd,
-                 int xStart, int xEnd, uint32_t* out, uint32_t* nodesPerPixel, Counters* counters)
+                 int xStart, int xEnd, uint32_t* out, uint32_t* nodesPerPixel, Counters* counters, int sampleFirst, int sampleCount)
 {
+    // sampleFirst / sampleCount: renderBlock runs all samples (0, samples); renderBlockFull (Game1.cs:320-374) is the
+    // same loop body run for ONE sample -- still divided by `samples` (:352) -- into a buffer of its own.
     t_cnt = counters;
     const Vec camPos = A3(cam->position), llc = A3(cam->lower_left), horiz = A3(cam->horizontal), vert = A3(cam->vertical);
     const int samples = p->samples;
@@ -849,7 +851,7 @@ void renderBlock(const orc_scene* s, const Surface* world, const orc_camera* cam
             RngKey key;
             key.seed = p->seed;
             key.pixel = (uint32_t)x + (uint32_t)y * (uint32_t)p->width;
-            for (int i = 0; i < samples; i++) {
+            for (int i = sampleFirst; i < sampleFirst + sampleCount; i++) {
                 key.sample = (uint32_t)i;
                 key.node = 0;
                 uint32_t jw = AuxWord(key, 0);
@@ -1061,8 +1063,8 @@ int32_t orc_scene_bvh_leaf_order(const orc_scene* s, int32_t* out, int32_t cap)
     return n;
 }
 
-int orc_render(const orc_scene* s, const orc_camera* cam, const orc_params* p, uint32_t* out, uint32_t* nodesPerPixel,
-               orc_stats* stats)
+static int RenderSamples(const orc_scene* s, const orc_camera* cam, const orc_params* p, uint32_t* out, uint32_t* nodesPerPixel,
+                         orc_stats* stats, int sampleFirst, int sampleCount)
 {
     if (!s || !cam || !p || !out) { g_error = "null argument"; return -1; }
     if (p->width <= 0 || p->height <= 0 || p->samples <= 0) { g_error = "width, height and samples must be positive"; return -1; }
@@ -1088,7 +1090,7 @@ int orc_render(const orc_scene* s, const orc_camera* cam, const orc_params* p, u
         int ye = y0 + band * (i + 1);
         if (i == n - 1 && !p->drop_remainder_rows) ye = y1;
         if (ye <= ys) continue;
-        pool.emplace_back(renderBlock, s, world, cam, p, ys, ye, x0, x1, out, nodesPerPixel, &counters[i]);
+        pool.emplace_back(renderBlock, s, world, cam, p, ys, ye, x0, x1, out, nodesPerPixel, &counters[i], sampleFirst, sampleCount);
     }
     for (auto& t : pool) t.join();
     auto t1 = std::chrono::steady_clock::now();
@@ -1105,6 +1107,43 @@ int orc_render(const orc_scene* s, const orc_camera* cam, const orc_params* p, u
         stats->seconds = std::chrono::duration<double>(t1 - t0).count();
         stats->threads_used = n;
     }
+    return 0;
+}
+
+int orc_render(const orc_scene* s, const orc_camera* cam, const orc_params* p, uint32_t* out, uint32_t* nodesPerPixel,
+               orc_stats* stats)
+{
+    return RenderSamples(s, cam, p, out, nodesPerPixel, stats, 0, p ? p->samples : 0);
+}
+
+// The "mix buffer" technique (Game1.cs:174-175, :382-388, :320-374, :209-220): every thread renders the WHOLE picture
+// with one sample into a buffer of its own -- the colour still divided by `samples` (:352), then gamma and packing --
+// and when all are done buffer1Data (default Colors: all zero) takes them in one after the other:
+// new Color(buffer1Data.ToVector3() / 2 + buffer.ToVector3() / 2).  Thread b's System.Random becomes sample index b of
+// the shared counter RNG; the reference's List.Add from Parallel.For leaves the order of the buffers to chance, here it
+// is the thread order.
+int orc_render_mix_buffers(const orc_scene* s, const orc_camera* cam, const orc_params* p, int32_t n_buffers, uint32_t* out, orc_stats* stats)
+{
+    if (!p || n_buffers < 1) { g_error = "n_buffers must be positive"; return -1; }
+    const size_t n = (size_t)p->width * (size_t)p->height;
+    std::vector<uint32_t> buffer(n);
+    for (size_t i = 0; i < n; i++) out[i] = 0u;   // new Color[width * height]
+    orc_stats total = {}, one = {};
+    for (int32_t b = 0; b < n_buffers; b++) {
+        int rc = RenderSamples(s, cam, p, buffer.data(), nullptr, &one, b, 1);
+        if (rc != 0) return rc;
+        total.rays_path += one.rays_path; total.rays_shadow += one.rays_shadow; total.rays_redundant += one.rays_redundant;
+        total.box_tests += one.box_tests; total.sphere_tests += one.sphere_tests; total.tri_tests += one.tri_tests;
+        total.rect_tests += one.rect_tests; total.hit_nodes += one.hit_nodes; total.seconds += one.seconds; total.threads_used = one.threads_used;
+        for (size_t i = 0; i < n; i++) {
+            // Color.ToVector3(): (R / 255f, G / 255f, B / 255f)
+            Vec tempBuffCol = V((float)(out[i] & 255u) / 255.0f, (float)((out[i] >> 8) & 255u) / 255.0f, (float)((out[i] >> 16) & 255u) / 255.0f);
+            Vec currBuffCol = V((float)(buffer[i] & 255u) / 255.0f, (float)((buffer[i] >> 8) & 255u) / 255.0f, (float)((buffer[i] >> 16) & 255u) / 255.0f);
+            Vec newBuffCol = (tempBuffCol / 2) + (currBuffCol / 2);
+            out[i] = PackColor(newBuffCol.X, newBuffCol.Y, newBuffCol.Z);
+        }
+    }
+    if (stats) *stats = total;
     return 0;
 }
 

@@ -75,6 +75,9 @@ int32_t orc_scene_bvh_leaf_order(const orc_scene*, int32_t* out, int32_t cap);
 /* 0 ok; <0 error (-1 bad argument, -2 the reference would throw for this configuration). */
 int orc_render(const orc_scene*, const orc_camera*, const orc_params*, uint32_t* rgba_out,
                uint32_t* nodes_per_pixel_or_null, orc_stats* stats_or_null);
+/* The mix-buffer technique (Game1.cs:174-175, :209-220, :320-388): n_buffers one-sample renders of the whole picture,
+ * each divided by p->samples as the reference does, mixed pairwise into `out` in 8-bit colour. */
+int orc_render_mix_buffers(const orc_scene* s, const orc_camera* cam, const orc_params* p, int32_t n_buffers, uint32_t* out, orc_stats* stats);
 const char* orc_last_error(void);
 
 /* Constructors of the host-side classes, for known-answer tests. */

@@ -75,6 +75,7 @@ SYMBOLS = [
     ("srt_render_progressive", C.c_int, [_CTX, C.POINTER(RenderParams), C.c_void_p, C.c_int]),
     ("srt_progress", C.c_int, [_CTX, C.POINTER(C.c_int), C.POINTER(C.c_int)]),
     ("srt_read_preview", C.c_int, [_CTX, C.c_void_p]),
+    ("srt_render_mix_buffers", C.c_int, [_CTX, C.POINTER(RenderParams), C.c_int32, C.c_void_p]),
     ("srt_blur_array", C.c_int, [_CTX, C.c_void_p, C.c_int32, C.c_int32, C.c_float, C.c_int32]),
     ("srt_contrast_blur_array", C.c_int, [_CTX, C.c_void_p, C.c_int32, C.c_int32, C.c_float, C.c_float, C.c_int32]),
     ("srt_despeckle", C.c_int, [_CTX, C.c_void_p, C.c_int32, C.c_int32, C.c_float, C.c_float, C.c_int32]),

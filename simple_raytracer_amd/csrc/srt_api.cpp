@@ -32,6 +32,8 @@ struct srt_ctx {
     size_t out_capacity = 0;  // pixels
     unsigned long long* d_stats = nullptr;
     uint32_t* d_counter = nullptr;        // work counter of the persistent trace kernel
+    uint32_t* d_mix = nullptr;            // one buffer of the mix-buffer technique
+    size_t mix_capacity = 0;              // in pixels
     float* d_mail = nullptr;              // scratch of -DSRT_TIMELINE builds (per-wavefront clock records)
     float* d_samples = nullptr;           // per-(sample, pixel) colours of one pass, 12 bytes each
     size_t samples_capacity = 0;          // bytes
@@ -123,7 +125,7 @@ int collect_stats(srt_ctx* c)
 
 // min_passes > 1 (progressive renders): at least that many passes, each followed by a preview in d_out, a copy of it
 // to pinned memory and an event.
-int launch(srt_ctx* c, const srt_render_params* p, uint32_t* d_out, size_t capacity, hipStream_t stream, bool counted, int min_passes = 1)
+int launch(srt_ctx* c, const srt_render_params* p, uint32_t* d_out, size_t capacity, hipStream_t stream, bool counted, int min_passes = 1, int mix_buffers = 0)
 {
     if (!c->committed) return fail(c, SRT_E_STATE, "srt_commit_scene has not been called");
     if (!c->has_camera) return fail(c, SRT_E_STATE, "srt_set_camera has not been called");
@@ -152,6 +154,18 @@ int launch(srt_ctx* c, const srt_render_params* p, uint32_t* d_out, size_t capac
     uint64_t per_pass = fit < by_items ? fit : by_items;
     if (per_pass < 1) per_pass = 1;
     if (per_pass > (uint64_t)ra.samples) per_pass = (uint64_t)ra.samples;
+    if (mix_buffers > 0) {
+        if (ra.layout != 0 || ra.world_size != 1) return fail(c, SRT_E_INVALID, "the mix-buffer technique renders whole frames (SRT_LAYOUT_FRAME, world_size 1)");
+        if ((uint32_t)ra.mode != MODE_COLOR) return fail(c, SRT_E_INVALID, "the mix-buffer technique calls GetRayColor (SRT_MODE_COLOR)");
+        per_pass = 1;
+        if ((size_t)need > c->mix_capacity) {
+            SRT_HIP(c, hipDeviceSynchronize());
+            if (c->d_mix) (void)hipFree(c->d_mix);
+            c->d_mix = nullptr; c->mix_capacity = 0;
+            SRT_HIP(c, hipMalloc((void**)&c->d_mix, (size_t)need * sizeof(uint32_t)));
+            c->mix_capacity = (size_t)need;
+        }
+    }
     const bool progressive = min_passes > 1;
     if (progressive) {
         uint64_t share = ((uint64_t)ra.samples + (uint64_t)min_passes - 1) / (uint64_t)min_passes;
@@ -184,6 +198,25 @@ int launch(srt_ctx* c, const srt_render_params* p, uint32_t* d_out, size_t capac
     }
     SRT_HIP(c, hipEventRecord(c->ev_begin, stream));
     const SceneView view = scene_view(c);
+    if (mix_buffers > 0) {
+        // renderBlockFull (Game1.cs:320-374) once per buffer: one sample -- sample index b of the counter RNG stands for
+        // thread b's System.Random -- divided by `samples`, gamma, packing; then the pairwise mix of Game1.cs:209-220
+        for (int b = 0; b < mix_buffers; b++) {
+            ra.sample_first = (uint32_t)b;
+            ra.sample_count = 1u;
+            ra.n_items = ra.n_work;
+            hipError_t e = launch_trace(view, ra, c->world_kind == SRT_WORLD_BVHNODE, counted, c->d_samples, c->d_stats, c->d_counter, c->d_mail, stream);
+            if (e != hipSuccess) return hip_fail(c, e, "trace kernel launch");
+            e = launch_resolve(ra, c->d_samples, c->d_running, c->d_mix, true, true, 0.0f, stream);
+            if (e != hipSuccess) return hip_fail(c, e, "resolve kernel launch");
+            e = launch_mix(d_out, c->d_mix, (uint32_t)need, b == 0, stream);
+            if (e != hipSuccess) return hip_fail(c, e, "mix kernel launch");
+        }
+        c->passes_total = 0;
+        SRT_HIP(c, hipEventRecord(c->ev_end, stream));
+        c->stats_pending = true;
+        return SRT_OK;
+    }
     int pass = 0;
     for (uint32_t s0 = 0; s0 < (uint32_t)ra.samples; s0 += (uint32_t)per_pass, pass++) {
         ra.sample_first = s0;
@@ -217,7 +250,7 @@ int ensure_out(srt_ctx* c, size_t pixels)
     return SRT_OK;
 }
 
-int render_blocking(srt_ctx* c, const srt_render_params* p, uint32_t* rgba_out, bool counted)
+int render_blocking(srt_ctx* c, const srt_render_params* p, uint32_t* rgba_out, bool counted, int mix_buffers = 0)
 {
     if (!c) return SRT_E_INVALID;
     if (!rgba_out) return fail(c, SRT_E_INVALID, "rgba_out is NULL");
@@ -229,7 +262,7 @@ int render_blocking(srt_ctx* c, const srt_render_params* p, uint32_t* rgba_out, 
     if (rc != SRT_OK) return rc;
     rc = collect_stats(c);  // a blocking render reports its own counters only
     if (rc != SRT_OK) return rc;
-    rc = launch(c, p, c->d_out, c->out_capacity, c->stream, counted);
+    rc = launch(c, p, c->d_out, c->out_capacity, c->stream, counted, 1, mix_buffers);
     if (rc != SRT_OK) return rc;
     SRT_HIP(c, hipMemcpyAsync(rgba_out, c->d_out, (size_t)n * sizeof(uint32_t), hipMemcpyDeviceToHost, c->stream));
     SRT_HIP(c, hipStreamSynchronize(c->stream));
@@ -288,6 +321,7 @@ void srt_destroy(srt_ctx* c)
     if (c->d_stats) hipFree(c->d_stats);
     if (c->d_counter) hipFree(c->d_counter);
     if (c->d_mail) hipFree(c->d_mail);
+    if (c->d_mix) hipFree(c->d_mix);
     if (c->d_samples) hipFree(c->d_samples);
     if (c->d_running) hipFree(c->d_running);
     if (c->h_pinned) hipHostFree(c->h_pinned);
@@ -527,6 +561,13 @@ int post_filter(srt_ctx* c, int filter, uint32_t* array, int32_t width, int32_t 
 }  // namespace
 
 extern "C" {
+
+int srt_render_mix_buffers(srt_ctx* ctx, const srt_render_params* p, int32_t n_buffers, uint32_t* rgba_out)
+{
+    if (!ctx) return SRT_E_INVALID;
+    if (n_buffers < 1 || n_buffers > 65536) return fail(ctx, SRT_E_INVALID, "n_buffers must be within 1..65536");
+    return render_blocking(ctx, p, rgba_out, false, n_buffers);
+}
 
 int srt_blur_array(srt_ctx* ctx, uint32_t* array, int32_t width, int32_t height, float weight, int32_t passes)
 {

@@ -683,6 +683,20 @@ __global__ void __launch_bounds__(kBlock) resolve_kernel(RenderArgs ra, const f3
     }
 }
 
+// The mix-buffer technique's last step (Game1.cs:209-220): buffer1Data[i] = new Color(buffer1Data[i].ToVector3() / 2 +
+// buffer[i].ToVector3() / 2), one buffer after the other; buffer1Data starts as default Colors (all zero).
+__global__ void __launch_bounds__(kBlock) mix_kernel(uint32_t* __restrict__ frame, const uint32_t* __restrict__ buffer, uint32_t n, int first)
+{
+    uint32_t i = blockIdx.x * (uint32_t)kBlock + threadIdx.x;
+    if (i >= n) return;
+    const uint32_t a = first ? 0u : frame[i], b = buffer[i];
+    // Color.ToVector3(): (R / 255f, G / 255f, B / 255f); Vector3 / 2 multiplies by 0.5
+    const f3 ta = mk3((float)(a & 255u) / 255.0f, (float)((a >> 8) & 255u) / 255.0f, (float)((a >> 16) & 255u) / 255.0f);
+    const f3 tb = mk3((float)(b & 255u) / 255.0f, (float)((b >> 8) & 255u) / 255.0f, (float)((b >> 16) & 255u) / 255.0f);
+    const f3 m = add3(scale3(ta, 0.5f), scale3(tb, 0.5f));
+    frame[i] = pack_color(m.x, m.y, m.z);
+}
+
 // Rank 0 of a multi-GPU job: pixel (x, y) of the frame lives in tile t = tx + ty*tiles_x, which
 // rank t % world rendered as its (t / world)-th tile.
 __global__ void __launch_bounds__(kBlock) assemble_kernel(RenderArgs ra, const uint32_t* __restrict__ gathered, size_t stride, uint32_t* __restrict__ frame)
@@ -802,6 +816,13 @@ hipError_t launch_resolve(const RenderArgs& ra, const float* d_samples, float* d
     dim3 grid((ra.n_work + kBlock - 1) / kBlock), block(kBlock);
     hipLaunchKernelGGL(resolve_kernel, grid, block, 0, stream, ra, reinterpret_cast<const f3*>(d_samples), reinterpret_cast<f3*>(d_running),
                        d_out, first_pass ? 1 : 0, last_pass ? 1 : 0, preview_scale);
+    return hipGetLastError();
+}
+
+hipError_t launch_mix(uint32_t* d_frame, const uint32_t* d_buffer, uint32_t n_pixels, bool first, hipStream_t stream)
+{
+    if (n_pixels == 0u) return hipSuccess;
+    hipLaunchKernelGGL(mix_kernel, dim3((n_pixels + kBlock - 1) / kBlock), dim3(kBlock), 0, stream, d_frame, d_buffer, n_pixels, first ? 1 : 0);
     return hipGetLastError();
 }
 

@@ -101,6 +101,14 @@ class Renderer:
             return out.reshape(height, width)
         return out
 
+    def render_mix_buffers(self, width, height, n_buffers, **kw):
+        """The reference's mixBufferTechnique (Game1.cs:174-175, :209-220, :320-388): n_buffers one-sample renders of the
+        whole frame, each divided by `samples`, mixed pairwise in 8-bit colour -> (height, width) uint32."""
+        p = self.params(width, height, **kw)
+        out = np.zeros(width * height, dtype=np.uint32)
+        self._check(self._lib.srt_render_mix_buffers(self._ctx, C.byref(p), int(n_buffers), out.ctypes.data_as(C.c_void_p)))
+        return out.reshape(height, width)
+
     def render_device(self, p, device_ptr, capacity_pixels, stream=None):
         """Launches the render into device memory on `stream` (a hipStream_t as int; 0/None = HIP's default stream)
         without synchronising."""

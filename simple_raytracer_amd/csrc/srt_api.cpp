@@ -544,17 +544,25 @@ int post_filter(srt_ctx* c, int filter, uint32_t* array, int32_t width, int32_t 
     SRT_HIP(c, hipSetDevice(c->device));
     const size_t bytes = (size_t)width * (size_t)height * sizeof(uint32_t);
     uint32_t* d[2] = {nullptr, nullptr};
+    uint32_t* d_progress = nullptr;
+    const size_t progress_bytes = post_progress_bytes();
+    uint32_t alarm = 0u;
     hipError_t e = hipMalloc((void**)&d[0], bytes);
     if (e == hipSuccess) e = hipMalloc((void**)&d[1], bytes);
+    if (e == hipSuccess) e = hipMalloc((void**)&d_progress, progress_bytes);
+    if (e == hipSuccess) e = hipMemsetAsync(d_progress, 0, progress_bytes, c->stream);
     if (e == hipSuccess) e = hipMemcpyAsync(d[0], array, bytes, hipMemcpyHostToDevice, c->stream);
     int from = 0;
     for (int32_t i = 0; i < passes && e == hipSuccess; i++, from ^= 1)
-        e = launch_post_filter(filter, d[from], d[from ^ 1], width, height, weight, param, c->stream);
+        e = launch_post_filter(filter, d[from], d[from ^ 1], width, height, weight, param, d_progress, c->stream);
     if (e == hipSuccess) e = hipMemcpyAsync(array, d[from], bytes, hipMemcpyDeviceToHost, c->stream);
+    if (e == hipSuccess) e = hipMemcpyAsync(&alarm, reinterpret_cast<char*>(d_progress) + progress_bytes - sizeof(uint32_t), sizeof(uint32_t), hipMemcpyDeviceToHost, c->stream);
     if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
     if (d[0]) (void)hipFree(d[0]);
     if (d[1]) (void)hipFree(d[1]);
+    if (d_progress) (void)hipFree(d_progress);
     if (e != hipSuccess) return hip_fail(c, e, "post-process filter");
+    if (alarm != 0u) return fail(c, SRT_E_HIP, "post-process filter: a band of rows gave up waiting for the band above it; the picture is incomplete");
     return SRT_OK;
 }
 

@@ -23,8 +23,12 @@ size_t trace_timeline_offset();   // experiments: where a -DSRT_TIMELINE build l
 hipError_t launch_resolve(const RenderArgs& ra, const float* d_samples, float* d_running, uint32_t* d_out, bool first_pass, bool last_pass,
                           float preview_scale, hipStream_t stream);
 // One in-place pass of a post-process filter (SRT_POST_*): d_in is the picture before the pass and stays untouched,
-// d_out receives the picture after it.  weight is clamped here; param = contrast / threshold.
-hipError_t launch_post_filter(int filter, const uint32_t* d_in, uint32_t* d_out, int width, int height, float weight, float param, hipStream_t stream);
+// d_out receives the picture after it.  weight is clamped here; param = contrast / threshold.  d_progress:
+// post_progress_bytes() of device memory, zeroed by the caller before the first pass; its last word is non-zero
+// afterwards if a band gave up waiting for the one above it (the picture is then incomplete).
+size_t post_progress_bytes();
+hipError_t launch_post_filter(int filter, const uint32_t* d_in, uint32_t* d_out, int width, int height, float weight, float param,
+                              uint32_t* d_progress, hipStream_t stream);
 // d_frame[i] = Color(d_frame[i].ToVector3() / 2 + d_buffer[i].ToVector3() / 2) (Game1.cs:209-220); first: d_frame counts as all zero.
 hipError_t launch_mix(uint32_t* d_frame, const uint32_t* d_buffer, uint32_t n_pixels, bool first, hipStream_t stream);
 hipError_t launch_assemble(const RenderArgs& ra, const uint32_t* d_gathered, size_t stride, uint32_t* d_frame, hipStream_t stream);

@@ -7,16 +7,20 @@
 // with the same x + 2y can be computed together, because everything (x, y) reads was finished at x + 2y - 1 at the
 // latest and everything that reads its old value comes later.
 //
-// post_band_kernel gives every interior row of a band (up to 1024 rows) one thread of a single workgroup.  At step t the
-// thread of local row r handles column 1 + t - 2r.  It keeps the old values it needs (its own row and the row below,
-// from the untouched input picture) in registers as a sliding window, its left neighbour's new value in a register,
-// and takes the three new values of the row above from a 4-deep ring in LDS that the thread above wrote one to three
-// steps earlier; one barrier per step.  The first row of a band reads the finished row above it from the output
-// picture, so bands run one after the other.  The output picture starts as a copy of the input, and a pixel is written
-// only when its value changes.
+// post_band_kernel cuts the interior rows into bands of 128; every band is one workgroup, every row one thread.  At step
+// t the thread of local row r handles column 1 + t - 2r.  It keeps the old values it needs (its own row and the row
+// below, from the untouched input picture) in registers as a sliding window, its left neighbour's new value in a
+// register, and takes the three new values of the row above from a 4-deep ring in LDS that the thread above wrote one
+// to three steps earlier; one barrier per step.  The bands of a picture run at the same time, each behind the one above
+// it: the first row of a band reads the row above from the output picture, and the thread of a band's last row
+// publishes every 16 columns (release store of a counter in global memory) how far that row is; thread 0 of the band
+// below waits (acquire loads) until the columns it needs are there.  Nothing waits for a band below, so the bands form a
+// pipeline that cannot lock up as long as all of them are resident, which the launcher sees to (at most 512 workgroups
+// per launch); a poll count bounds the wait all the same and raises an alarm the host turns into an error.  The output
+// picture starts as a copy of the input, and a pixel is written only when its value changes.
 //
-// It is a latency-bound kernel by construction (W + 2 * rows dependent steps on one compute unit): 8 bytes read and at
-// most 4 written per pixel, far from any roofline.  The arithmetic is the reference's, float for float: bytes to float,
+// It is a latency-bound kernel by construction (about W + 2H dependent steps): 8 bytes read and at most 4 written per
+// pixel, far from any roofline.  The arithmetic is the reference's, float for float: bytes to float,
 // the sum of the eight neighbours left to right in the order the source adds them, Vector3 / 8 as a multiplication by
 // 0.125, `new Color(v / 255)` as a true division followed by (int)(c * 255) with clamping.
 #include <hip/hip_runtime.h>
@@ -28,7 +32,10 @@ namespace srt {
 
 namespace {
 
-constexpr int kPostRows = 1024;   // rows per band = threads of the workgroup
+constexpr int kBandRows = 128;                        // rows per band = threads of a workgroup
+constexpr int kPostPublish = 16;                      // a band reports the progress of its last row every so many columns
+constexpr int kMaxBands = 512;                        // workgroups of one launch: all resident at once, so none waits for one that cannot start
+constexpr unsigned long long kPostMaxPolls = 1ull << 26;   // watchdog of the wait for the band above
 
 __device__ __forceinline__ f3 bytes_of(uint32_t c) { return mk3((float)(c & 255u), (float)((c >> 8) & 255u), (float)((c >> 16) & 255u)); }
 __device__ __forceinline__ uint32_t color_of(f3 v) { return pack_color(v.x / 255.0f, v.y / 255.0f, v.z / 255.0f); }
@@ -86,19 +93,22 @@ __device__ __forceinline__ uint32_t filtered(uint32_t current, const Window& w, 
 }
 
 template <int FILTER>
-__global__ void __launch_bounds__(kPostRows) post_band_kernel(const uint32_t* __restrict__ in, uint32_t* out, int width, int height, int row0,
-                                                               int rows, float weight, float param)
+__global__ void __launch_bounds__(kBandRows) post_band_kernel(const uint32_t* __restrict__ in, uint32_t* out, int width, int height, int first_row,
+                                                               float weight, float param, uint32_t* progress)
 {
-    __shared__ uint32_t ring[kPostRows][4];   // new values of the last four columns of every row of the band
+    __shared__ uint32_t ring[kBandRows][4];   // new values of the last four columns of every row of the band
+    const int band = (int)blockIdx.x, row0 = first_row + band * kBandRows;
+    const int rows = height - 1 - row0 < kBandRows ? height - 1 - row0 : kBandRows;
     const int r = (int)threadIdx.x, y = row0 + r;
     const bool mine = r < rows;
     const uint32_t* own = in + (size_t)(mine ? y : row0) * (size_t)width;
     const uint32_t* below = own + width;
     const uint32_t* above_in = own - width;
-    const uint32_t* above_out = out + (size_t)(row0 - 1) * (size_t)width;   // finished before this band started
+    const uint32_t* above_out = out + (size_t)(row0 - 1) * (size_t)width;   // the last row of the band above (or row 0)
     // the window of old values slides along with the thread's column
     uint32_t cur = 0u, right = 0u, d_left = 0u, d_mid = 0u, d_right = 0u, left_new = 0u;
     if (mine) { cur = own[1]; right = own[2]; d_left = below[0]; d_mid = below[1]; d_right = below[2]; left_new = own[0]; }
+    uint32_t known = band == 0 ? 0x7FFFFFFFu : 0u;   // thread 0: columns the band above is known to have finished in its last row
     const int steps = (width - 2) + 2 * (rows - 1);
     for (int t = 0; t < steps; t++) {
         const int x = 1 + t - 2 * r;
@@ -107,6 +117,15 @@ __global__ void __launch_bounds__(kPostRows) post_band_kernel(const uint32_t* __
             w.left = left_new; w.right = right;
             w.down = d_mid; w.left_down = d_left; w.right_down = d_right;
             if (r == 0) {
+                // needs columns x - 1 .. x + 1 of the row above in their final state
+                const uint32_t need = (uint32_t)(x + 1 < width - 2 ? x + 1 : width - 2);
+                if (known < need) {
+                    unsigned long long polls = 0ull;
+                    do {
+                        known = __hip_atomic_load(&progress[band - 1], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT);
+                        if (++polls > kPostMaxPolls) { __hip_atomic_store(&progress[kMaxBands], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); break; }
+                    } while (known < need);
+                }
                 w.left_up = above_out[x - 1]; w.up = above_out[x]; w.right_up = above_out[x + 1];
             } else {
                 // columns 0 and width - 1 are never filtered: their "new" value is the input's
@@ -118,6 +137,9 @@ __global__ void __launch_bounds__(kPostRows) post_band_kernel(const uint32_t* __
             if (now != cur) out[(size_t)y * (size_t)width + (size_t)x] = now;
             ring[r][x & 3] = now;
             left_new = now;
+            // the band below reads this band's last row: tell it every kPostPublish columns how far the row is
+            if (r == rows - 1 && ((x & (kPostPublish - 1)) == 0 || x == width - 2))
+                __hip_atomic_store(&progress[band], (uint32_t)x, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
             // slide: the loads are for the next step and have the barrier to arrive in
             cur = right;
             d_left = d_mid; d_mid = d_right;
@@ -129,17 +151,26 @@ __global__ void __launch_bounds__(kPostRows) post_band_kernel(const uint32_t* __
 
 }  // namespace
 
-hipError_t launch_post_filter(int filter, const uint32_t* d_in, uint32_t* d_out, int width, int height, float weight, float param, hipStream_t stream)
+size_t post_progress_bytes() { return (size_t)(kMaxBands + 1) * sizeof(uint32_t); }
+
+hipError_t launch_post_filter(int filter, const uint32_t* d_in, uint32_t* d_out, int width, int height, float weight, float param,
+                              uint32_t* d_progress, hipStream_t stream)
 {
     hipError_t e = hipMemcpyAsync(d_out, d_in, (size_t)width * (size_t)height * sizeof(uint32_t), hipMemcpyDeviceToDevice, stream);
     if (e != hipSuccess) return e;
     if (width < 3 || height < 3) return hipSuccess;   // no interior pixel
     weight = weight < 0.0f ? 0.0f : (weight > 1.0f ? 1.0f : weight);   // Math.Clamp(weight, 0, 1)
-    for (int row0 = 1; row0 <= height - 2; row0 += kPostRows) {
-        const int rows = height - 1 - row0 < kPostRows ? height - 1 - row0 : kPostRows;
-        if (filter == SRT_POST_BLUR) hipLaunchKernelGGL((post_band_kernel<SRT_POST_BLUR>), dim3(1), dim3(kPostRows), 0, stream, d_in, d_out, width, height, row0, rows, weight, param);
-        else if (filter == SRT_POST_CONTRAST_BLUR) hipLaunchKernelGGL((post_band_kernel<SRT_POST_CONTRAST_BLUR>), dim3(1), dim3(kPostRows), 0, stream, d_in, d_out, width, height, row0, rows, weight, param);
-        else hipLaunchKernelGGL((post_band_kernel<SRT_POST_DESPECKLE>), dim3(1), dim3(kPostRows), 0, stream, d_in, d_out, width, height, row0, rows, weight, param);
+    for (int row0 = 1; row0 <= height - 2; row0 += kMaxBands * kBandRows) {
+        const int rows = height - 1 - row0;
+        int bands = (rows + kBandRows - 1) / kBandRows;
+        if (bands > kMaxBands) bands = kMaxBands;
+        // progress[b]: last finished column of band b's last row; progress[kMaxBands]: the watchdog's alarm, which the
+        // caller clears once and reads at the end
+        e = hipMemsetAsync(d_progress, 0, (size_t)bands * sizeof(uint32_t), stream);
+        if (e != hipSuccess) return e;
+        if (filter == SRT_POST_BLUR) hipLaunchKernelGGL((post_band_kernel<SRT_POST_BLUR>), dim3(bands), dim3(kBandRows), 0, stream, d_in, d_out, width, height, row0, weight, param, d_progress);
+        else if (filter == SRT_POST_CONTRAST_BLUR) hipLaunchKernelGGL((post_band_kernel<SRT_POST_CONTRAST_BLUR>), dim3(bands), dim3(kBandRows), 0, stream, d_in, d_out, width, height, row0, weight, param, d_progress);
+        else hipLaunchKernelGGL((post_band_kernel<SRT_POST_DESPECKLE>), dim3(bands), dim3(kBandRows), 0, stream, d_in, d_out, width, height, row0, weight, param, d_progress);
         e = hipGetLastError();
         if (e != hipSuccess) return e;
     }

@@ -4,11 +4,13 @@ cancel) against the oracle's sequential loop on one host core (the reference's f
 
     python tools/post_bench.py
 """
+import os
 import sys
 import time
 
-sys.path.insert(0, ".")
-sys.path.insert(0, "tests")
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
 import simple_raytracer_amd as srt  # noqa: E402
 from oracle import orc  # noqa: E402  (the CPU side of the comparison)
 from test_post_filters import random_image  # noqa: E402

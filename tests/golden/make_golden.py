@@ -41,8 +41,26 @@ def render(entry):
     return img, nodes, np.array([st["rays_path"], st["rays_shadow"], st["hit_nodes"]], dtype=np.uint64)
 
 
+# The steps after the render: one pass of each post-process filter over the 16-spp golden picture, and the mix-buffer
+# technique (3 buffers, samples = 2) on the default scene.
+POST_NAME = "post_filters_and_mix_buffers_64x36"
+POST_ARGS = {"despeckle": (1.0, 120.0), "blur": (0.5,), "contrast_blur": (0.7, 20.0), "mix": (3, 2, 4, 1)}   # mix: buffers, samples, depth, seed
+
+
+def render_post():
+    picture = np.load(os.path.join(HERE, "default_color_16spp_64x36.npz"))["image"]
+    spec = helpers.default_spec()
+    mixed, _ = spec.oracle_scene().render_mix_buffers(spec.oracle_camera(64, 36), 64, 36, POST_ARGS["mix"][0], samples=POST_ARGS["mix"][1],
+                                                      max_depth=POST_ARGS["mix"][2], seed=POST_ARGS["mix"][3])
+    return {"picture": picture, "despeckle": orc.Despeckle(picture, *POST_ARGS["despeckle"]), "blur": orc.BlurArray(picture, *POST_ARGS["blur"]),
+            "contrast_blur": orc.ContrastBlurArray(picture, *POST_ARGS["contrast_blur"]), "mix": mixed}
+
+
 if __name__ == "__main__":
     only = sys.argv[1:]          # optional: names to (re)generate
+    if not only or POST_NAME in only:
+        np.savez_compressed(os.path.join(HERE, POST_NAME + ".npz"), **render_post())
+        print(POST_NAME)
     for name, entry in GOLDEN.items():
         if only and name not in only:
             continue

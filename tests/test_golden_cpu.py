@@ -7,7 +7,7 @@ import pytest
 
 import helpers
 import simple_raytracer_amd as srt
-from golden.make_golden import GOLDEN, render
+from golden.make_golden import GOLDEN, POST_NAME, render, render_post
 
 
 @pytest.mark.parametrize("name", sorted(GOLDEN))
@@ -32,3 +32,11 @@ def test_kernel_source_reproduces_golden(emu_lib, name):
     if mode == srt.MODE_COLOR:
         st = r.stats()
         assert [st["rays_path"], st["rays_shadow"], st["hit_nodes"]] == g["counts"].tolist()
+
+
+def test_oracle_reproduces_post_golden(oracle):
+    g = np.load(os.path.join(helpers.GOLDEN, POST_NAME + ".npz"))
+    now = render_post()
+    for key in ("despeckle", "blur", "contrast_blur", "mix"):
+        assert (now[key] == g[key]).all(), key
+    assert (g["despeckle"] != g["picture"]).any() and (g["blur"] != g["picture"]).any()

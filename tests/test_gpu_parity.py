@@ -328,3 +328,17 @@ def test_gpu_random_render_parameters_match_kernel_source_on_cpu(gpu, emu_lib):
     import gpu_fuzz
     emu = srt.Renderer(library=emu_lib, strict=False)
     assert gpu_fuzz.run(gpu, emu, 60, 2024) == []
+
+
+def test_gpu_reproduces_post_golden(gpu):
+    """Filters and mix-buffer technique against the committed fixture (no oracle involved)."""
+    from golden.make_golden import POST_ARGS, POST_NAME
+    g = np.load(os.path.join(helpers.GOLDEN, POST_NAME + ".npz"))
+    assert (gpu.despeckle(g["picture"], *POST_ARGS["despeckle"]) == g["despeckle"]).all()
+    assert (gpu.blur_array(g["picture"], *POST_ARGS["blur"]) == g["blur"]).all()
+    assert (gpu.contrast_blur_array(g["picture"], *POST_ARGS["contrast_blur"]) == g["contrast_blur"]).all()
+    world, lights, cam = helpers.default_spec().host(64, 36)
+    gpu.set_scene(world, lights, cam)
+    n, samples, depth, seed = POST_ARGS["mix"]
+    lsb, _ = helpers.max_lsb_diff(gpu.render_mix_buffers(64, 36, n, samples=samples, max_depth=depth, seed=seed), g["mix"])
+    assert lsb <= 1

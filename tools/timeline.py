@@ -1,4 +1,4 @@
-"""Per-wavefront clock records of a -DSRT_TIMELINE build of the library (tools/_timeline/libsrt.so): when each
+"""Per-wavefront clock records of a -DSRT_TIMELINE build of the library (make -C simple_raytracer_amd/csrc timeline -> tools/_timeline/libsrt.so): when each
 wavefront started, found the item counter exhausted, and finished.
 
     SRT_LIBRARY=tools/_timeline/libsrt.so SRT_TIMELINE_FILE=/tmp/tl.bin python tools/timeline.py [c3|c4|c5] [spp ...]

@@ -4,7 +4,7 @@
  * like Game1.Update does every frame (:188-201), and save the frame (:239-244; here a binary PPM instead of a PNG).
  * It shows the call sequence a maintainer's P/Invoke layer makes and needs nothing but include/srt.h.
  *
- *   game1_host [width height samples max_depth seed out.ppm]
+ *   game1_host [width height samples max_depth seed out.ppm blur_passes]
  */
 #include <math.h>
 #include <stdio.h>
@@ -48,6 +48,7 @@ int main(int argc, char** argv)
     int samples = argc > 3 ? atoi(argv[3]) : 500, max_depth = argc > 4 ? atoi(argv[4]) : 4;  /* :43, :78 */
     unsigned seed = argc > 5 ? (unsigned)strtoul(argv[5], NULL, 10) : 1u;
     const char* path = argc > 6 ? argv[6] : "game1.ppm";
+    int blur_passes = argc > 7 ? atoi(argv[7]) : 0;                                         /* Game1.cs:49: blurPasses = 0 */
 
     srt_ctx* ctx = NULL;
     srt_config cfg = {0, 0};
@@ -94,6 +95,13 @@ int main(int argc, char** argv)
     CHECK(srt_get_stats(ctx, &st));
     fprintf(stderr, "%dx%d, %d spp, depth %d: %.3f ms on the device, %llu rays, %.1f Mrays/s, %lu polls\n", width, height, samples,
             max_depth, st.kernel_ms, (unsigned long long)st.rays_path, (double)st.rays_path / st.kernel_ms / 1e3, polls);
+
+    /* Game1.Update, once the render is done (Game1.cs:226-232): blurPasses times Sorting.Despeckle(buffer1Data, width,
+       height, blurWeight = 1, speckleThreshold = 200) */
+    if (blur_passes > 0) {
+        CHECK(srt_despeckle(ctx, frame, width, height, 1.0f, 200.0f, blur_passes));
+        fprintf(stderr, "despeckled, %d passes\n", blur_passes);
+    }
 
     /* rows in buffer order, as the reference saves its Color[] (buffer row 0 is the bottom of the camera's view and
        the top of the saved picture: the scene is set up for that, see testrender.jpg) */

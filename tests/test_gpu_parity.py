@@ -202,6 +202,10 @@ def test_gpu_c_host_example_matches_python_host(gpu, tmp_path):
     gpu.set_scene(world, lights, cam, world_kind=srt.WORLD_BVHNODE)
     img = gpu.render(w, h, samples=spp, max_depth=depth, seed=seed)
     assert np.array_equal(rgb, srt.rgba_to_rgb8(img))
+    # with blurPasses = 2 (Game1.cs:226-232) the C host despeckles the frame before it saves it
+    subprocess.run([exe, str(w), str(h), str(spp), str(depth), str(seed), str(out), "2"], check=True, timeout=100)
+    rgb = np.frombuffer(out.read_bytes()[len(header):], dtype=np.uint8).reshape(h, w, 3)
+    assert np.array_equal(rgb, srt.rgba_to_rgb8(gpu.despeckle(img, 1.0, 200.0, passes=2)))
 
 
 import random_scenes  # noqa: E402

@@ -120,6 +120,7 @@ int collect_stats(srt_ctx* c)
     for (int i = 0; i < 16; i++) c->stats.section_cycles[i] = s[16 + i];
     c->stats.kernel_ms = ms;
     c->stats_pending = false;
+    if (s[11] != 0ull) return fail(c, SRT_E_HIP, "trace kernel: a wavefront gave up waiting for a ray subtree that another lane took over; the picture is incomplete");
     return SRT_OK;
 }
 

@@ -95,6 +95,8 @@ struct TreeFork {
     __device__ __forceinline__ bool donated(int32_t lvl, uint32_t child) const { return lvl < kForkLevels && ((given >> (2 * lvl + (int32_t)child - 1)) & 1u) != 0u; }
     __device__ __forceinline__ void wait_for(uint32_t child) { wait = child; }
 };
+constexpr uint32_t kMaxStalledTrips = 4096u;   // trips in a row with only waiting lanes before a wavefront gives up (never reached unless a colour is lost)
+constexpr int kStatsAlarm = 11;                // stats word that counts wavefronts that gave up
 constexpr int kForkMinDepth = 2;       // only subtrees that can still grow (remaining depth >= this)
 constexpr size_t kMailPerWave = 64;     // -DSRT_TIMELINE builds: float4 entries of scratch per wavefront of the grid
 
@@ -344,6 +346,7 @@ __global__ void __launch_bounds__(kBlock, SMALL ? SRT_WAVES_PER_SIMD : SRT_WAVES
         int32_t deliver = -1;      // >= 0: this lane walks a subtree for lane (deliver & 63); deliver >> 8 is the giver's bit for it
         uint32_t open = open_children(ln, phase, frames, sc);
         uint32_t* my_pair = &lds_pair[wave * 64];
+        uint32_t stalled = 0u;   // wave-uniform: trips in a row in which no lane had anything to run
         // a tree ended: its colour is a sample, or waits for the giver
         auto finish = [&](f3 ret) {
             if (deliver >= 0) { ln.former = ret; phase = LANE_DELIVER; }
@@ -366,8 +369,12 @@ __global__ void __launch_bounds__(kBlock, SMALL ? SRT_WAVES_PER_SIMD : SRT_WAVES
             const unsigned long long m_trace = __ballot(phase == LANE_TRACE || phase == LANE_RETURN), m_light = __ballot(phase == LANE_LIGHT);
             if ((m_trace | m_light) == 0ull) {
                 if (__ballot(phase == LANE_WAIT) == 0ull) break;
-                continue;   // givers and helpers that meet at the top of the loop
+                // givers and helpers that meet at the top of the loop: every such trip hands over at least one colour, so
+                // a long run of them means a colour got lost -- leave with an alarm instead of spinning on the GPU
+                if (++stalled > kMaxStalledTrips) { if (lane == 0u) atomicAdd(&stats[kStatsAlarm], 1ull); break; }
+                continue;
             }
+            stalled = 0u;
             if (m_trace != 0ull) {
                 if (phase == LANE_RETURN) {
                     f3 ret;
@@ -497,6 +504,7 @@ __global__ void __launch_bounds__(kBlock, SRT_WAVES_PER_SIMD_MESH) mesh_trace_ke
     bool sharing = false;      // wave-uniform: no new items, lanes share their trees
     uint32_t* my_pair = &lds_pair[wave * 64];
     uint32_t handed = 0u;
+    uint32_t stalled = 0u;     // wave-uniform: trips in a row in which no lane had anything to run
 
     uint32_t sect[4] = {0u, 0u, 0u, 0u};
     typename std::conditional<COUNT, ClockProf, NoProf>::type prof;
@@ -554,7 +562,12 @@ __global__ void __launch_bounds__(kBlock, SRT_WAVES_PER_SIMD_MESH) mesh_trace_ke
         const int n_up = __popcll(__ballot(phase == MESH_RETURN || (phase == MESH_IDLE && !dry)));
         const int n_wait = __popcll(__ballot(phase == MESH_WAIT || phase == LANE_DELIVER));
         if (n_walk + n_closest + n_shadow + n_up + n_wait == 0) break;
-        if (n_walk + n_closest + n_shadow + n_up == 0) continue;     // givers and helpers that meet at the top of the loop
+        if (n_walk + n_closest + n_shadow + n_up == 0) {
+            // givers and helpers that meet at the top of the loop (see trace_kernel's closing loop for the alarm)
+            if (++stalled > kMaxStalledTrips) { if (lane == 0u) atomicAdd(&stats[kStatsAlarm], 1ull); break; }
+            continue;
+        }
+        stalled = 0u;
 
         if (n_walk >= walk_vote || (n_walk >= n_closest && n_walk >= n_shadow && n_walk >= n_up)) {
             // ---- a quantum of traversal

@@ -14,6 +14,7 @@
 #include <algorithm>
 
 #include "../../simple_raytracer_amd/csrc/srt_path.h"
+#include "../../simple_raytracer_amd/csrc/srt_post.h"
 #include "../../simple_raytracer_amd/csrc/srt_scene.h"
 
 using namespace srt;
@@ -91,6 +92,31 @@ void run_items(const SceneView& sc, const RenderArgs& ra, uint32_t i0, uint32_t 
     tot->v[3] += cnt.box_tests; tot->v[4] += cnt.sphere_tests; tot->v[5] += cnt.tri_tests; tot->v[6] += cnt.rect_tests;
 }
 
+}  // namespace
+
+namespace {
+
+// The post-process filters: the kernel's per-pixel function (srt_post.h) over the picture in the reference's order,
+// row-major and in place, so that a pixel sees the new values of its left neighbour and of the row above.
+template <int FILTER>
+static void post_pass(uint32_t* a, int32_t w, int32_t h, float weight, float param)
+{
+    weight = weight < 0.0f ? 0.0f : (weight > 1.0f ? 1.0f : weight);
+    for (int32_t y = 1; y < h - 1; y++)
+        for (int32_t x = 1; x < w - 1; x++) {
+            Window win;
+            win.left = a[x - 1 + y * w]; win.right = a[x + 1 + y * w];
+            win.up = a[x + (y - 1) * w]; win.down = a[x + (y + 1) * w];
+            win.left_up = a[x - 1 + (y - 1) * w]; win.right_up = a[x + 1 + (y - 1) * w];
+            win.left_down = a[x - 1 + (y + 1) * w]; win.right_down = a[x + 1 + (y + 1) * w];
+            a[x + y * w] = filtered<FILTER>(a[x + y * w], win, weight, param);
+        }
+}
+static int post_check(srt_ctx* c, uint32_t* a, int32_t w, int32_t h, int32_t passes)
+{
+    if (!c || !a || w < 1 || h < 1 || passes < 1) return SRT_E_INVALID;
+    return SRT_OK;
+}
 }  // namespace
 
 extern "C" {
@@ -192,6 +218,25 @@ int srt_render_counted(srt_ctx* c, const srt_render_params* p, uint32_t* out) { 
 // Test hook (not part of include/srt.h): the item order of one pass.  For every work item of a pass over all of
 // p->samples with the last `scatter_samples` in scattered order: slots[item] = its sample-buffer slot, pixels[item] =
 // x + y * width, or 0xFFFFFFFF for a padding pixel of an edge tile.  Returns the number of items.
+int srt_blur_array(srt_ctx* c, uint32_t* a, int32_t w, int32_t h, float weight, int32_t passes)
+{
+    if (int rc = post_check(c, a, w, h, passes)) return rc;
+    for (int32_t i = 0; i < passes; i++) post_pass<SRT_POST_BLUR>(a, w, h, weight, 0.0f);
+    return SRT_OK;
+}
+int srt_contrast_blur_array(srt_ctx* c, uint32_t* a, int32_t w, int32_t h, float weight, float contrast, int32_t passes)
+{
+    if (int rc = post_check(c, a, w, h, passes)) return rc;
+    for (int32_t i = 0; i < passes; i++) post_pass<SRT_POST_CONTRAST_BLUR>(a, w, h, weight, contrast);
+    return SRT_OK;
+}
+int srt_despeckle(srt_ctx* c, uint32_t* a, int32_t w, int32_t h, float weight, float threshold, int32_t passes)
+{
+    if (int rc = post_check(c, a, w, h, passes)) return rc;
+    for (int32_t i = 0; i < passes; i++) post_pass<SRT_POST_DESPECKLE>(a, w, h, weight, threshold);
+    return SRT_OK;
+}
+
 int64_t srt_emu_item_order(srt_ctx* c, const srt_render_params* p, uint32_t scatter_samples, uint32_t* slots, uint32_t* pixels, uint64_t capacity)
 {
     RenderArgs ra;

@@ -89,6 +89,21 @@ def test_oracle_pictures_without_interior_are_unchanged(oracle):
         assert (oracle.BlurArray(img, 1.0) == img).all()
 
 
+# ---- the kernel's per-pixel arithmetic on the CPU (tests/emu runs it in the reference's row-major order) ---------
+@pytest.mark.parametrize("h,w", [(3, 3), (4, 9), (37, 53), (130, 257)])
+def test_kernel_source_filters_match_oracle(emu_lib, oracle, h, w):
+    emu = srt.Renderer(library=emu_lib, strict=False)
+    img = random_image(h, w, 11 * h + w)
+    for weight, threshold in ((1.0, 200.0), (0.15, 120.0)):
+        assert (emu.despeckle(img, weight, threshold) == oracle.Despeckle(img, weight, threshold)).all()
+    for weight in (1.0, 0.3, 1.7, -0.5):
+        assert (emu.blur_array(img, weight) == oracle.BlurArray(img, weight)).all()
+    for weight, contrast in ((1.0, 40.0), (0.5, 5.0), (0.8, 0.0)):
+        assert (emu.contrast_blur_array(img, weight, contrast) == oracle.ContrastBlurArray(img, weight, contrast)).all()
+    twice = oracle.Despeckle(oracle.Despeckle(img, 0.8, 150.0), 0.8, 150.0)
+    assert (emu.despeckle(img, 0.8, 150.0, passes=2) == twice).all()
+
+
 # ---- GPU parity ------------------------------------------------------------------------------
 SIZES = [(3, 3), (4, 9), (37, 53), (64, 64), (130, 257), (1080, 1920), (1100, 64), (2100, 40)]   # (height, width); > 1024 rows: several bands
 

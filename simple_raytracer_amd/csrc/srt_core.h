@@ -713,6 +713,16 @@ struct Frame {
 
 enum : uint32_t { MODE_COLOR = 0u, MODE_NORMAL = 1u, MODE_DEPTH = 2u, MODE_LIGHTS = 3u, MODE_DIFFUSE = 4u, MODE_REFLECTION = 5u };
 
+// The mix-buffer technique's step for one pixel (Game1.cs:215-218): new Color(a.ToVector3() / 2 + b.ToVector3() / 2), with
+// Color.ToVector3() = (R / 255f, G / 255f, B / 255f) and Vector3 / 2 a multiplication by 0.5.
+SRT_HD uint32_t mix_colors(uint32_t a, uint32_t b)
+{
+    const f3 ta = mk3((float)(a & 255u) / 255.0f, (float)((a >> 8) & 255u) / 255.0f, (float)((a >> 16) & 255u) / 255.0f);
+    const f3 tb = mk3((float)(b & 255u) / 255.0f, (float)((b >> 8) & 255u) / 255.0f, (float)((b >> 16) & 255u) / 255.0f);
+    const f3 m = add3(scale3(ta, 0.5f), scale3(tb, 0.5f));
+    return pack_color(m.x, m.y, m.z);
+}
+
 // Maps a pixel slot of this rank to its pixel.  Slots enumerate this rank's tiles (tile t belongs to
 // rank t % world_size), and inside a tile 8x8 blocks, so that 64 consecutive slots are an 8x8
 // pixel block.  Returns false for padding pixels of edge tiles.

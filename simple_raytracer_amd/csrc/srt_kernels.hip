@@ -702,12 +702,7 @@ __global__ void __launch_bounds__(kBlock) mix_kernel(uint32_t* __restrict__ fram
 {
     uint32_t i = blockIdx.x * (uint32_t)kBlock + threadIdx.x;
     if (i >= n) return;
-    const uint32_t a = first ? 0u : frame[i], b = buffer[i];
-    // Color.ToVector3(): (R / 255f, G / 255f, B / 255f); Vector3 / 2 multiplies by 0.5
-    const f3 ta = mk3((float)(a & 255u) / 255.0f, (float)((a >> 8) & 255u) / 255.0f, (float)((a >> 16) & 255u) / 255.0f);
-    const f3 tb = mk3((float)(b & 255u) / 255.0f, (float)((b >> 8) & 255u) / 255.0f, (float)((b >> 16) & 255u) / 255.0f);
-    const f3 m = add3(scale3(ta, 0.5f), scale3(tb, 0.5f));
-    frame[i] = pack_color(m.x, m.y, m.z);
+    frame[i] = mix_colors(first ? 0u : frame[i], buffer[i]);
 }
 
 // Rank 0 of a multi-GPU job: pixel (x, y) of the frame lives in tile t = tx + ty*tiles_x, which

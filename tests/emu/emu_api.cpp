@@ -162,7 +162,7 @@ int srt_commit_scene(srt_ctx* c, int world_kind)
     return SRT_OK;
 }
 
-int srt_render(srt_ctx* c, const srt_render_params* p, uint32_t* out)
+static int render_passes(srt_ctx* c, const srt_render_params* p, uint32_t* out, int mix_buffers)
 {
     if (!c->committed || !c->has_camera) { c->error = "scene or camera missing"; return SRT_E_STATE; }
     RenderArgs ra;
@@ -175,11 +175,17 @@ int srt_render(srt_ctx* c, const srt_render_params* p, uint32_t* out)
     std::vector<Totals> tot(n);
     const bool exact = c->world_kind == SRT_WORLD_BVHNODE;
     // Passes of at most 3 samples, so that the running-sum path of the resolve step is exercised too.
-    const uint32_t per_pass = 3;
+    // mix_buffers > 0: the mix-buffer technique, one sample (index b) per buffer, each buffer finished on its own and
+    // mixed into `out` (as srt_render_mix_buffers does with the trace, resolve and mix kernels)
+    const uint32_t per_pass = mix_buffers > 0 ? 1 : 3;
+    const uint32_t total = mix_buffers > 0 ? (uint32_t)mix_buffers : (uint32_t)ra.samples;
     std::vector<f3> samples((size_t)per_pass * ra.n_work), running(ra.n_work);
-    for (uint32_t s0 = 0; s0 < (uint32_t)ra.samples; s0 += per_pass) {
+    std::vector<uint32_t> buffer(mix_buffers > 0 ? (size_t)ra.width * (size_t)ra.height : 0);
+    uint32_t* frame = out;
+    if (mix_buffers > 0) out = buffer.data();
+    for (uint32_t s0 = 0; s0 < total; s0 += per_pass) {
         ra.sample_first = s0;
-        ra.sample_count = std::min<uint32_t>(per_pass, (uint32_t)ra.samples - s0);
+        ra.sample_count = mix_buffers > 0 ? 1u : std::min<uint32_t>(per_pass, (uint32_t)ra.samples - s0);
         set_item_order(ra, 2u);   // as the GPU launcher does for scenes without a traversal stack
         ra.n_items = ra.n_work * ra.sample_count;
         std::vector<std::thread> pool;
@@ -193,7 +199,7 @@ int srt_render(srt_ctx* c, const srt_render_params* p, uint32_t* out)
             });
         }
         for (auto& th : pool) th.join();
-        const bool first = s0 == 0, last = s0 + ra.sample_count >= (uint32_t)ra.samples;
+        const bool first = mix_buffers > 0 || s0 == 0, last = mix_buffers > 0 || s0 + ra.sample_count >= (uint32_t)ra.samples;
         for (uint32_t wp = 0; wp < ra.n_work; wp++) {   // what resolve_kernel does per thread
             int32_t x, y;
             uint32_t oi;
@@ -206,12 +212,20 @@ int srt_render(srt_ctx* c, const srt_render_params* p, uint32_t* out)
             if (last) out[oi] = finish_color(acc);
             else running[wp] = acc;
         }
+        if (mix_buffers > 0)
+            for (size_t i = 0; i < buffer.size(); i++) frame[i] = mix_colors(s0 == 0 ? 0u : frame[i], buffer[i]);   // mix_kernel
     }
     uint64_t s[7] = {0, 0, 0, 0, 0, 0, 0};
     for (auto& t : tot) for (int i = 0; i < 7; i++) s[i] += t.v[i];
     c->stats.rays_path = s[0]; c->stats.rays_shadow = s[1]; c->stats.hit_nodes = s[2];
     c->stats.box_tests = s[3]; c->stats.sphere_tests = s[4]; c->stats.tri_tests = s[5]; c->stats.rect_tests = s[6];
     return SRT_OK;
+}
+int srt_render(srt_ctx* c, const srt_render_params* p, uint32_t* out) { return render_passes(c, p, out, 0); }
+int srt_render_mix_buffers(srt_ctx* c, const srt_render_params* p, int32_t n_buffers, uint32_t* out)
+{
+    if (n_buffers < 1 || p->layout != 0 || p->world_size > 1) return SRT_E_INVALID;
+    return render_passes(c, p, out, n_buffers);
 }
 int srt_render_counted(srt_ctx* c, const srt_render_params* p, uint32_t* out) { return srt_render(c, p, out); }
 

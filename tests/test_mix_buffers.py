@@ -37,6 +37,20 @@ def test_oracle_divides_every_buffer_by_samples(oracle):
     assert abs(np.median(r_d[lit] / r_b[lit]) - 0.5) < 0.05
 
 
+@pytest.mark.parametrize("n_buffers,samples,kind", [(1, 1, srt.WORLD_BVHNODE), (4, 2, srt.WORLD_SURFACELIST), (3, 500, srt.WORLD_BVHNODE)])
+def test_kernel_source_mix_buffers_match_oracle(emu_lib, oracle, n_buffers, samples, kind):
+    """The kernel source on the CPU (tests/emu): one-sample frames, resolve, mix -- against the oracle."""
+    spec = helpers.default_spec()
+    w, h = 64, 36
+    emu = srt.Renderer(library=emu_lib, strict=False)
+    world, lights, cam = spec.host(w, h)
+    emu.set_scene(world, lights, cam, world_kind=kind)
+    img = emu.render_mix_buffers(w, h, n_buffers, samples=samples, max_depth=5, seed=5)
+    ref, ost = spec.oracle_scene().render_mix_buffers(spec.oracle_camera(w, h), w, h, n_buffers, samples=samples, max_depth=5, seed=5, world_kind=kind)
+    assert (img == ref).all()
+    assert emu.stats()["rays_path"] == ost["rays_path"]
+
+
 @pytest.mark.gpu
 @pytest.mark.parametrize("n_buffers,samples,kind", [(1, 1, srt.WORLD_BVHNODE), (3, 1, srt.WORLD_BVHNODE), (8, 4, srt.WORLD_SURFACELIST), (5, 500, srt.WORLD_BVHNODE)])
 def test_gpu_mix_buffers_match_oracle(gpu_renderer_factory, oracle, n_buffers, samples, kind):

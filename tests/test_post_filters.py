@@ -105,7 +105,7 @@ def test_kernel_source_filters_match_oracle(emu_lib, oracle, h, w):
 
 
 # ---- GPU parity ------------------------------------------------------------------------------
-SIZES = [(3, 3), (4, 9), (37, 53), (64, 64), (130, 257), (1080, 1920), (1100, 64), (2100, 40)]   # (height, width); > 1024 rows: several bands
+SIZES = [(3, 3), (4, 9), (37, 53), (64, 64), (130, 257), (1080, 1920), (1100, 64), (2100, 40), (66000, 8)]   # (height, width); bands of 128 rows; more than 512 bands: two launches
 
 
 @pytest.fixture(scope="module")

@@ -34,7 +34,7 @@ struct srt_ctx {
     uint32_t* d_counter = nullptr;        // work counter of the persistent trace kernel
     uint32_t* d_mix = nullptr;            // one buffer of the mix-buffer technique
     size_t mix_capacity = 0;              // in pixels
-    float* d_mail = nullptr;              // scratch of -DSRT_TIMELINE builds (per-wavefront clock records)
+    float* d_timeline = nullptr;              // scratch of -DSRT_TIMELINE builds (per-wavefront clock records)
     float* d_samples = nullptr;           // per-(sample, pixel) colours of one pass, 12 bytes each
     size_t samples_capacity = 0;          // bytes
     float* d_running = nullptr;           // per-pixel running sums, only for renders that need several passes
@@ -108,7 +108,7 @@ int collect_stats(srt_ctx* c)
 #ifdef SRT_TIMELINE
     if (const char* path = std::getenv("SRT_TIMELINE_FILE")) {
         std::vector<unsigned long long> tl(4096 * 4);
-        hipMemcpy(tl.data(), reinterpret_cast<char*>(c->d_mail) + srt::trace_timeline_offset(), tl.size() * 8, hipMemcpyDeviceToHost);
+        hipMemcpy(tl.data(), reinterpret_cast<char*>(c->d_timeline) + srt::trace_timeline_offset(), tl.size() * 8, hipMemcpyDeviceToHost);
         if (FILE* f = std::fopen(path, "wb")) { std::fwrite(tl.data(), 8, tl.size(), f); std::fclose(f); }
     }
 #endif
@@ -206,7 +206,7 @@ int launch(srt_ctx* c, const srt_render_params* p, uint32_t* d_out, size_t capac
             ra.sample_first = (uint32_t)b;
             ra.sample_count = 1u;
             ra.n_items = ra.n_work;
-            hipError_t e = launch_trace(view, ra, c->world_kind == SRT_WORLD_BVHNODE, counted, c->d_samples, c->d_stats, c->d_counter, c->d_mail, stream);
+            hipError_t e = launch_trace(view, ra, c->world_kind == SRT_WORLD_BVHNODE, counted, c->d_samples, c->d_stats, c->d_counter, c->d_timeline, stream);
             if (e != hipSuccess) return hip_fail(c, e, "trace kernel launch");
             e = launch_resolve(ra, c->d_samples, c->d_running, c->d_mix, true, true, 0.0f, stream);
             if (e != hipSuccess) return hip_fail(c, e, "resolve kernel launch");
@@ -223,7 +223,7 @@ int launch(srt_ctx* c, const srt_render_params* p, uint32_t* d_out, size_t capac
         ra.sample_first = s0;
         ra.sample_count = (uint32_t)ra.samples - s0 < (uint32_t)per_pass ? (uint32_t)ra.samples - s0 : (uint32_t)per_pass;
         ra.n_items = ra.n_work * ra.sample_count;
-        hipError_t e = launch_trace(view, ra, c->world_kind == SRT_WORLD_BVHNODE, counted, c->d_samples, c->d_stats, c->d_counter, c->d_mail, stream);
+        hipError_t e = launch_trace(view, ra, c->world_kind == SRT_WORLD_BVHNODE, counted, c->d_samples, c->d_stats, c->d_counter, c->d_timeline, stream);
         if (e != hipSuccess) return hip_fail(c, e, "trace kernel launch");
         const uint32_t done = s0 + ra.sample_count;
         const float preview = progressive ? (float)ra.samples / (float)done : 0.0f;
@@ -298,7 +298,9 @@ int srt_create(const srt_config* cfg, srt_ctx** out)
               hipEventCreate(&c->ev_begin) == hipSuccess && hipEventCreate(&c->ev_end) == hipSuccess &&
               hipMalloc((void**)&c->d_stats, 32 * sizeof(unsigned long long)) == hipSuccess &&
               hipMalloc((void**)&c->d_counter, sizeof(uint32_t)) == hipSuccess &&
-              hipMalloc((void**)&c->d_mail, trace_mail_bytes()) == hipSuccess &&
+#ifdef SRT_TIMELINE
+              hipMalloc((void**)&c->d_timeline, trace_timeline_bytes()) == hipSuccess &&
+#endif
               hipMemset(c->d_stats, 0, 32 * sizeof(unsigned long long)) == hipSuccess && hipDeviceSynchronize() == hipSuccess;
     if (!ok) {
         srt_destroy(c);
@@ -321,7 +323,7 @@ void srt_destroy(srt_ctx* c)
     if (c->d_out) hipFree(c->d_out);
     if (c->d_stats) hipFree(c->d_stats);
     if (c->d_counter) hipFree(c->d_counter);
-    if (c->d_mail) hipFree(c->d_mail);
+    if (c->d_timeline) hipFree(c->d_timeline);
     if (c->d_mix) hipFree(c->d_mix);
     if (c->d_samples) hipFree(c->d_samples);
     if (c->d_running) hipFree(c->d_running);

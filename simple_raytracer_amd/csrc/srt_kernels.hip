@@ -42,7 +42,7 @@ constexpr int kWaves = kBlock / 64;
 constexpr uint32_t kChunk = 256;       // items drawn from the global counter at a time
 constexpr uint32_t kScatterSamples = 2; // trace_kernel: samples at the end of a pass that are enumerated in scattered order
 constexpr int kTraceVote = 24;         // run the TRACE section while at least this many lanes want it
-constexpr int kMaxBlocks = 256 * 5;    // persistent grid: never more blocks than 5 per CU (the mailboxes are sized for it)
+constexpr int kMaxBlocks = 256 * 5;    // persistent grid: never more blocks than 5 per CU (the timeline records are sized for it)
 
 __device__ __forceinline__ unsigned long long wave_sum(unsigned long long v)
 {
@@ -98,7 +98,7 @@ struct TreeFork {
 constexpr uint32_t kMaxStalledTrips = 4096u;   // trips in a row with only waiting lanes before a wavefront gives up (never reached unless a colour is lost)
 constexpr int kStatsAlarm = 11;                // stats word that counts wavefronts that gave up
 constexpr int kForkMinDepth = 2;       // only subtrees that can still grow (remaining depth >= this)
-constexpr size_t kMailPerWave = 64;     // -DSRT_TIMELINE builds: float4 entries of scratch per wavefront of the grid
+constexpr size_t kTimelinePerWave = 64;     // -DSRT_TIMELINE builds: float4 entries of scratch per wavefront of the grid
 
 enum { LANE_DELIVER = 5 };
 
@@ -209,7 +209,7 @@ __device__ __forceinline__ void copy_words(q4* dst, const q4* src, uint32_t n)
 template <bool EXACT, bool COUNT, bool SMALL>
 __global__ void __launch_bounds__(kBlock, SMALL ? SRT_WAVES_PER_SIMD : SRT_WAVES_PER_SIMD_BIG) trace_kernel(SceneView gsc, RenderArgs ra, f3* __restrict__ samples,
                                                        unsigned long long* __restrict__ stats, uint32_t* __restrict__ work_counter,
-                                                       float4* __restrict__ mail /* -DSRT_TIMELINE builds only */, int trace_vote, uint32_t chunk, int share, uint32_t guide)
+                                                       float4* __restrict__ timeline /* -DSRT_TIMELINE builds only */, int trace_vote, uint32_t chunk, int share, uint32_t guide)
 {
     __shared__ float lds_frames[SMALL ? kWaves * kLdsFrameLevels * 14 * 64 : 1];
     __shared__ uint32_t lds_pair[kWaves * 64];   // handing over subtrees: giver lane by rank
@@ -414,8 +414,8 @@ __global__ void __launch_bounds__(kBlock, SMALL ? SRT_WAVES_PER_SIMD : SRT_WAVES
     }
 
 #ifdef SRT_TIMELINE
-    if (lane == 0u && mail != nullptr) {
-        unsigned long long* rec = reinterpret_cast<unsigned long long*>(mail + (size_t)1100 * kWaves * kMailPerWave) + ((size_t)blockIdx.x * kWaves + wave) * 4;
+    if (lane == 0u && timeline != nullptr) {
+        unsigned long long* rec = reinterpret_cast<unsigned long long*>(timeline + (size_t)1100 * kWaves * kTimelinePerWave) + ((size_t)blockIdx.x * kWaves + wave) * 4;
         rec[0] = tl_start; rec[1] = tl_dry; rec[2] = wall_clock64(); rec[3] = tl_trips;
     }
 #endif
@@ -469,7 +469,7 @@ constexpr int kWalkVote = 16, kWalkRounds = 1 << 24, kWalkSteps = 2;
 template <bool EXACT, bool COUNT>
 __global__ void __launch_bounds__(kBlock, SRT_WAVES_PER_SIMD_MESH) mesh_trace_kernel(SceneView sc, RenderArgs ra, f3* __restrict__ samples,
                                                             unsigned long long* __restrict__ stats, uint32_t* __restrict__ work_counter,
-                                                            float4* __restrict__ mail /* -DSRT_TIMELINE builds only */, int walk_vote, int rounds, int steps, uint32_t chunk, uint32_t guide, int share)
+                                                            float4* __restrict__ timeline /* -DSRT_TIMELINE builds only */, int walk_vote, int rounds, int steps, uint32_t chunk, uint32_t guide, int share)
 {
     __shared__ uint32_t lds_stack[kWaves * STACK_DEPTH * 64];
     __shared__ uint32_t lds_pair[kWaves * 64];   // handing over subtrees: giver lane by rank
@@ -648,8 +648,8 @@ __global__ void __launch_bounds__(kBlock, SRT_WAVES_PER_SIMD_MESH) mesh_trace_ke
     }
 
 #ifdef SRT_TIMELINE
-    if (lane == 0u && mail != nullptr) {
-        unsigned long long* rec = reinterpret_cast<unsigned long long*>(mail + (size_t)1100 * kWaves * kMailPerWave) + ((size_t)blockIdx.x * kWaves + wave) * 4;
+    if (lane == 0u && timeline != nullptr) {
+        unsigned long long* rec = reinterpret_cast<unsigned long long*>(timeline + (size_t)1100 * kWaves * kTimelinePerWave) + ((size_t)blockIdx.x * kWaves + wave) * 4;
         rec[0] = tl_start; rec[1] = tl_dry; rec[2] = wall_clock64(); rec[3] = tl_trips;
     }
 #endif
@@ -735,7 +735,7 @@ static uint32_t resident_blocks(K kernel)
 }
 
 hipError_t launch_trace(const SceneView& sc, const RenderArgs& ra_in, bool exact, bool counted, float* d_samples,
-                        unsigned long long* d_stats, uint32_t* d_work_counter, float* d_mail, hipStream_t stream)
+                        unsigned long long* d_stats, uint32_t* d_work_counter, float* d_timeline, hipStream_t stream)
 {
     if (ra_in.n_items == 0u) return hipSuccess;
     RenderArgs ra = ra_in;
@@ -786,12 +786,12 @@ hipError_t launch_trace(const SceneView& sc, const RenderArgs& ra_in, bool exact
     static const int walk_rounds = std::getenv("SRT_WALK_ROUNDS") ? std::atoi(std::getenv("SRT_WALK_ROUNDS")) : kWalkRounds;
     static const int walk_steps = std::getenv("SRT_WALK_STEPS") ? std::atoi(std::getenv("SRT_WALK_STEPS")) : kWalkSteps;
     static const bool allow_fork = !std::getenv("SRT_NO_SUBTREE_SHARING");
-    float4* mailboxes = reinterpret_cast<float4*>(d_mail);
+    float4* timeline = reinterpret_cast<float4*>(d_timeline);
     const int share = allow_fork && (uint32_t)ra.mode == MODE_COLOR ? 1 : 0;   // lanes share the last ray trees of a launch
     if (!stackless) {
         static const uint32_t mesh_scatter = std::getenv("SRT_MESH_SCATTER_SAMPLES") ? (uint32_t)std::atoi(std::getenv("SRT_MESH_SCATTER_SAMPLES")) : 0u;
         set_item_order(ra, mesh_scatter);
-#define SRT_LAUNCH_MESH(E, C) hipLaunchKernelGGL((mesh_trace_kernel<E, C>), grid, block, 0, stream, sc, ra, s, d_stats, d_work_counter, mailboxes, walk_vote, walk_rounds, walk_steps, chunk, guide, share)
+#define SRT_LAUNCH_MESH(E, C) hipLaunchKernelGGL((mesh_trace_kernel<E, C>), grid, block, 0, stream, sc, ra, s, d_stats, d_work_counter, timeline, walk_vote, walk_rounds, walk_steps, chunk, guide, share)
         if (exact) { if (counted) SRT_LAUNCH_MESH(true, true); else SRT_LAUNCH_MESH(true, false); }
         else { if (counted) SRT_LAUNCH_MESH(false, true); else SRT_LAUNCH_MESH(false, false); }
 #undef SRT_LAUNCH_MESH
@@ -804,7 +804,7 @@ hipError_t launch_trace(const SceneView& sc, const RenderArgs& ra_in, bool exact
     // short passes are better off with more of them: measured 5.83 -> 5.29 ms at 4 spp (all four), 9.14 -> 8.80 ms at 8 spp (three)
     const bool knob = std::getenv("SRT_SCATTER_SAMPLES") != nullptr;
     set_item_order(ra, knob ? scatter_samples : (ra.sample_count <= 4u ? ra.sample_count : (ra.sample_count <= 11u ? 3u : scatter_samples)));
-#define SRT_LAUNCH(E, C, S) hipLaunchKernelGGL((trace_kernel<E, C, S>), grid, block, 0, stream, sc, ra, s, d_stats, d_work_counter, mailboxes, vote, chunk, share, guide)
+#define SRT_LAUNCH(E, C, S) hipLaunchKernelGGL((trace_kernel<E, C, S>), grid, block, 0, stream, sc, ra, s, d_stats, d_work_counter, timeline, vote, chunk, share, guide)
     if (exact) {
         if (counted) { if (small) SRT_LAUNCH(true, true, true); else SRT_LAUNCH(true, true, false); }
         else { if (small) SRT_LAUNCH(true, false, true); else SRT_LAUNCH(true, false, false); }
@@ -816,8 +816,8 @@ hipError_t launch_trace(const SceneView& sc, const RenderArgs& ra_in, bool exact
     return hipGetLastError();
 }
 
-size_t trace_timeline_offset() { return (size_t)1100 * kWaves * kMailPerWave * sizeof(float4); }
-size_t trace_mail_bytes() { return (size_t)kMaxBlocks * kWaves * kMailPerWave * sizeof(float4); }
+size_t trace_timeline_offset() { return (size_t)1100 * kWaves * kTimelinePerWave * sizeof(float4); }
+size_t trace_timeline_bytes() { return (size_t)kMaxBlocks * kWaves * kTimelinePerWave * sizeof(float4); }
 
 hipError_t launch_resolve(const RenderArgs& ra, const float* d_samples, float* d_running, uint32_t* d_out, bool first_pass, bool last_pass,
                           float preview_scale, hipStream_t stream)

@@ -12,11 +12,11 @@ namespace srt {
 // rank's pixels.  d_samples: 3 floats per (sample, pixel), sample-major, ra.sample_count * ra.n_work entries.
 // d_stats: 32 x uint64 the kernel adds to: rays_path, rays_shadow, hit_nodes, box_tests, sphere_tests,
 // tri_tests, rect_tests, (unused).  d_work_counter: one uint32, reset by the launcher on `stream`.
-// d_mail: trace_mail_bytes() of device memory; only -DSRT_TIMELINE builds write to it (per-wavefront clock records).
+// d_timeline: trace_timeline_bytes() of device memory; only -DSRT_TIMELINE builds write to it (per-wavefront clock records).
 hipError_t launch_trace(const SceneView& sc, const RenderArgs& ra, bool exact, bool counted, float* d_samples,
-                        unsigned long long* d_stats, uint32_t* d_work_counter, float* d_mail, hipStream_t stream);
-size_t trace_mail_bytes();
-size_t trace_timeline_offset();   // experiments: where a -DSRT_TIMELINE build leaves its per-wavefront clock records in d_mail
+                        unsigned long long* d_stats, uint32_t* d_work_counter, float* d_timeline, hipStream_t stream);
+size_t trace_timeline_bytes();
+size_t trace_timeline_offset();   // experiments: where a -DSRT_TIMELINE build leaves its per-wavefront clock records in d_timeline
 // Adds the pass's samples to the per-pixel running sums (3 floats per pixel; untouched when the pass is both the
 // first and the last) and, on the last pass, writes the packed pixels.  preview_scale > 0: earlier passes write a
 // preview (running sum times preview_scale) to d_out as well.

@@ -725,12 +725,11 @@ __global__ void __launch_bounds__(kBlock) assemble_kernel(RenderArgs ra, const u
 template <class K>
 static uint32_t resident_blocks(K kernel)
 {
-    int per_cu = 0, dev = 0;
-    hipDeviceProp_t prop;
-    if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess ||
-        hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kernel, kBlock, 0) != hipSuccess || per_cu <= 0)
+    int per_cu = 0, dev = 0, cus = 0;
+    if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess ||
+        hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kernel, kBlock, 0) != hipSuccess || per_cu <= 0 || cus <= 0)
         return (uint32_t)kMaxBlocks;
-    uint32_t n = (uint32_t)per_cu * (uint32_t)prop.multiProcessorCount;
+    uint32_t n = (uint32_t)per_cu * (uint32_t)cus;
     return n < (uint32_t)kMaxBlocks ? n : (uint32_t)kMaxBlocks;
 }
 

@@ -12,7 +12,10 @@
 
 #include <algorithm>
 #include <cmath>
+#include <cstdlib>
 #include <cstring>
+#include <system_error>
+#include <thread>
 
 namespace srt {
 namespace {
@@ -45,6 +48,25 @@ inline Box surrounding(const Box& b0, const Box& b1)
     return r;
 }
 
+// Runs body(first, last) over [0, n) in slices on a few host threads (one thread below 64k items).
+template <class F>
+void parallel_slices(uint32_t n, F body)
+{
+    unsigned hw = std::thread::hardware_concurrency();
+    uint32_t parts = n < 65536u ? 1u : std::min<uint32_t>(hw ? hw : 1u, 16u);
+    if (parts <= 1) { body(0u, n); return; }
+    std::vector<std::thread> pool;
+    const uint32_t step = (n + parts - 1) / parts;
+    uint32_t first = 0;
+    try {
+        for (; first + step < n; first += step) pool.emplace_back(body, first, first + step);
+    } catch (const std::system_error&) {
+        // no further thread to be had: this one does the rest
+    }
+    body(first, n);
+    for (auto& t : pool) t.join();
+}
+
 inline q4 mkq(float x, float y, float z, float w) { q4 q; q.x = x; q.y = y; q.z = z; q.w = w; return q; }
 
 struct NodeRec {
@@ -59,15 +81,17 @@ void primitive_boxes(const HostScene& in, std::vector<Box>& pb)
 {
     const uint32_t nt = in.n_tris(), ns = in.n_spheres();
     pb.resize((size_t)nt + ns);
-    for (uint32_t i = 0; i < nt; i++) {
-        const float* p = &in.tri_pos[(size_t)i * 9];
-        Box b;
-        for (int k = 0; k < 3; k++) {
-            b.mx[k] = net_max(net_max(p[k], p[3 + k]), p[6 + k]);
-            b.mn[k] = net_min(net_min(p[k], p[3 + k]), p[6 + k]);
+    parallel_slices(nt, [&](uint32_t first, uint32_t last) {
+        for (uint32_t i = first; i < last; i++) {
+            const float* p = &in.tri_pos[(size_t)i * 9];
+            Box b;
+            for (int k = 0; k < 3; k++) {
+                b.mx[k] = net_max(net_max(p[k], p[3 + k]), p[6 + k]);
+                b.mn[k] = net_min(net_min(p[k], p[3 + k]), p[6 + k]);
+            }
+            pb[i] = b;
         }
-        pb[i] = b;
-    }
+    });
     for (uint32_t i = 0; i < ns; i++) {
         const float* s = &in.sph[(size_t)i * 4];
         Box b;
@@ -170,22 +194,36 @@ struct ReferenceBuilder {
 // ---------------------------------------------------------------------------------------
 // Binned SAH builder
 // ---------------------------------------------------------------------------------------
+// The build runs on several host threads and still produces the tree (node order, primitive order) that
+// one thread would: a node with at least `fork_min` primitives builds its left half in another thread.  No
+// thread allocates: a subtree over positions [lo, hi) of `ids` leaves its primitives, in leaf order, in those
+// positions, and the node that splits at position `mid` keeps its two children in entries 2 * mid - 2 and
+// 2 * mid - 1 of `scratch` (every split position belongs to exactly one node).  `compact` then writes the
+// nodes out in the depth-first order in which a single thread would have allocated them.
+// Each thread works on its own range of `ids`; the primitive boxes and centroids are only read.
 struct SahBuilder {
     enum { BINS = 16, LEAF_MAX = 4, DEPTH_LIMIT = 30 };
+    enum : uint32_t { FORK_FLOOR = 16384, FORK_SHARE = 16 };
     const std::vector<Box>& pb;
-    std::vector<uint32_t> ids;
+    std::vector<uint32_t> ids;                  // after run(): the primitives in leaf order
     std::vector<float> cx[3];
+    std::vector<NodeRec> scratch;
     std::vector<NodeRec> nodes;
-    std::vector<uint32_t> leaf_order;
+    std::vector<uint32_t>& leaf_order = ids;
     uint32_t max_depth = 0;
+    uint32_t fork_min = 0xFFFFFFFFu;
 
     explicit SahBuilder(const std::vector<Box>& boxes) : pb(boxes) {}
 
+    // minimum / maximum that keep the accumulator when the other value is a NaN, as fmin / fmax do, without the
+    // library call those cost in a build that honours NaNs
+    static float lower(float acc, float v) { return v < acc ? v : acc; }
+    static float upper(float acc, float v) { return v > acc ? v : acc; }
     static void grow(Box& b, const Box& o)
     {
         for (int k = 0; k < 3; k++) {
-            b.mn[k] = std::fmin(b.mn[k], o.mn[k]);
-            b.mx[k] = std::fmax(b.mx[k], o.mx[k]);
+            b.mn[k] = lower(b.mn[k], o.mn[k]);
+            b.mx[k] = upper(b.mx[k], o.mx[k]);
         }
     }
     static Box empty_box()
@@ -206,28 +244,30 @@ struct SahBuilder {
         while ((1u << l) < n) l++;
         return l;
     }
+    static int bin_of(float c, float lo_c, float scale)
+    {
+        int b = (int)((c - lo_c) * scale);
+        return b < 0 ? 0 : (b >= BINS ? BINS - 1 : b);
+    }
     void make_leaf(uint32_t lo, uint32_t hi, uint32_t slot)
     {
-        uint32_t first = (uint32_t)leaf_order.size();
         // keep insertion order inside a leaf; ties are settled by the order rank anyway
         std::sort(ids.begin() + lo, ids.begin() + hi);
-        for (uint32_t i = lo; i < hi; i++) leaf_order.push_back(ids[i]);
-        nodes[slot].desc = leaf_desc(first, hi - lo);
+        scratch[slot].desc = leaf_desc(lo, hi - lo);
     }
     void build(uint32_t lo, uint32_t hi, uint32_t slot, uint32_t depth)
     {
-        if (depth > max_depth) max_depth = depth;
         const uint32_t n = hi - lo;
         Box box = empty_box(), cb = empty_box();
         for (uint32_t i = lo; i < hi; i++) {
             grow(box, pb[ids[i]]);
             for (int k = 0; k < 3; k++) {
                 float c = cx[k][ids[i]];
-                cb.mn[k] = std::fmin(cb.mn[k], c);
-                cb.mx[k] = std::fmax(cb.mx[k], c);
+                cb.mn[k] = lower(cb.mn[k], c);
+                cb.mx[k] = upper(cb.mx[k], c);
             }
         }
-        nodes[slot].box = box;
+        scratch[slot].box = box;
         if (n <= 1) { make_leaf(lo, hi, slot); return; }
 
         // levels still available below this node; a balanced split needs ceil_log2(n / LEAF_MAX)
@@ -235,36 +275,47 @@ struct SahBuilder {
         uint32_t mid = 0;
         bool split = false;
         if (!must_balance) {
+            // one pass over the primitives fills the bins of all three axes
+            Box bb[3][BINS];
+            uint32_t bc[3][BINS];
+            float lo_c[3], scale[3];
+            bool live[3];
+            for (int axis = 0; axis < 3; axis++) {
+                float ext = cb.mx[axis] - cb.mn[axis];
+                live[axis] = ext > 0.0f;
+                lo_c[axis] = cb.mn[axis];
+                scale[axis] = live[axis] ? (float)BINS / ext : 0.0f;
+                for (int b = 0; b < BINS; b++) { bb[axis][b] = empty_box(); bc[axis][b] = 0; }
+            }
+            for (uint32_t i = lo; i < hi; i++) {
+                const uint32_t id = ids[i];
+                const Box& pbox = pb[id];
+                for (int axis = 0; axis < 3; axis++) {
+                    if (!live[axis]) continue;
+                    int b = bin_of(cx[axis][id], lo_c[axis], scale[axis]);
+                    bc[axis][b]++;
+                    grow(bb[axis][b], pbox);
+                }
+            }
             float best_cost = INFINITY;
             int best_axis = -1, best_bin = -1;
             for (int axis = 0; axis < 3; axis++) {
-                float lo_c = cb.mn[axis], ext = cb.mx[axis] - cb.mn[axis];
-                if (!(ext > 0.0f)) continue;
-                Box bb[BINS];
-                uint32_t bc[BINS];
-                for (int b = 0; b < BINS; b++) { bb[b] = empty_box(); bc[b] = 0; }
-                float scale = (float)BINS / ext;
-                for (uint32_t i = lo; i < hi; i++) {
-                    int b = (int)((cx[axis][ids[i]] - lo_c) * scale);
-                    b = b < 0 ? 0 : (b >= BINS ? BINS - 1 : b);
-                    bc[b]++;
-                    grow(bb[b], pb[ids[i]]);
-                }
+                if (!live[axis]) continue;
                 float right_area[BINS];
                 uint32_t right_cnt[BINS];
                 Box acc = empty_box();
                 uint32_t cnt = 0;
                 for (int b = BINS - 1; b > 0; b--) {
-                    grow(acc, bb[b]);
-                    cnt += bc[b];
+                    grow(acc, bb[axis][b]);
+                    cnt += bc[axis][b];
                     right_area[b] = half_area(acc);
                     right_cnt[b] = cnt;
                 }
                 acc = empty_box();
                 cnt = 0;
                 for (int b = 0; b < BINS - 1; b++) {
-                    grow(acc, bb[b]);
-                    cnt += bc[b];
+                    grow(acc, bb[axis][b]);
+                    cnt += bc[axis][b];
                     if (cnt == 0 || right_cnt[b + 1] == 0) continue;
                     float cost = half_area(acc) * (float)cnt + right_area[b + 1] * (float)right_cnt[b + 1];
                     if (cost < best_cost) { best_cost = cost; best_axis = axis; best_bin = b; }
@@ -274,13 +325,10 @@ struct SahBuilder {
                 float leaf_cost = half_area(box) * (float)n;
                 float split_cost = 1.0f * half_area(box) + best_cost;  // one box-pair visit ~ one primitive test
                 if (n > (uint32_t)LEAF_MAX || split_cost < leaf_cost) {
-                    float lo_c = cb.mn[best_axis], ext = cb.mx[best_axis] - cb.mn[best_axis];
-                    float scale = (float)BINS / ext;
-                    auto it = std::partition(ids.begin() + lo, ids.begin() + hi, [&](uint32_t id) {
-                        int b = (int)((cx[best_axis][id] - lo_c) * scale);
-                        b = b < 0 ? 0 : (b >= BINS ? BINS - 1 : b);
-                        return b <= best_bin;
-                    });
+                    const float l = lo_c[best_axis], sc = scale[best_axis];
+                    const std::vector<float>& c = cx[best_axis];
+                    auto it = std::partition(ids.begin() + lo, ids.begin() + hi,
+                                             [&](uint32_t id) { return bin_of(c[id], l, sc) <= best_bin; });
                     mid = (uint32_t)(it - ids.begin());
                     split = mid > lo && mid < hi;
                 }
@@ -297,11 +345,39 @@ struct SahBuilder {
             std::nth_element(ids.begin() + lo, ids.begin() + mid, ids.begin() + hi,
                              [&](uint32_t a, uint32_t b) { return cx[axis][a] < cx[axis][b] || (cx[axis][a] == cx[axis][b] && a < b); });
         }
-        uint32_t pair = (uint32_t)nodes.size();
-        nodes.resize(nodes.size() + 2);
-        nodes[slot].desc = pair;
+        const uint32_t pair = 2u * mid - 2u;
+        scratch[slot].desc = pair;
+        if (n >= fork_min) {
+            std::thread left;
+            try {
+                left = std::thread([this, lo, mid, pair, depth] { build(lo, mid, pair, depth + 1); });
+            } catch (const std::system_error&) {
+                // no thread to be had: this one does both halves
+            }
+            if (left.joinable()) {
+                struct Join { std::thread& th; ~Join() { th.join(); } } join{left};
+                build(mid, hi, pair + 1, depth + 1);
+                return;
+            }
+        }
         build(lo, mid, pair, depth + 1);
         build(mid, hi, pair + 1, depth + 1);
+    }
+    // Writes node `from` of the scratch tree, and everything below it, to `slot` of the final tree.
+    void compact(uint32_t from, uint32_t slot, uint32_t depth)
+    {
+        const NodeRec& nd = scratch[from];
+        if (depth > max_depth) max_depth = depth;
+        nodes[slot].box = nd.box;
+        if (nd.desc & DESC_LEAF) {
+            nodes[slot].desc = nd.desc;
+        } else {
+            uint32_t pair = (uint32_t)nodes.size();
+            nodes.resize(nodes.size() + 2);
+            nodes[slot].desc = pair;
+            compact(nd.desc, pair, depth + 1);
+            compact(nd.desc + 1, pair + 1, depth + 1);
+        }
     }
     void run()
     {
@@ -312,10 +388,20 @@ struct SahBuilder {
             ids[i] = i;
             for (int k = 0; k < 3; k++) cx[k][i] = 0.5f * pb[i].mn[k] + 0.5f * pb[i].mx[k];
         }
+        // at most 2 * FORK_SHARE - 1 nodes hold n / FORK_SHARE primitives or more: that bounds the threads
+        fork_min = std::max<uint32_t>(FORK_FLOOR, n / FORK_SHARE);
+        if (const char* e = std::getenv("SRT_BUILD_FORK_MIN")) {
+            long v = std::atol(e);
+            fork_min = v > 0 ? (uint32_t)std::max<long>(v, (long)(n / 64)) : 0xFFFFFFFFu;   // 0: one thread
+        }
+        scratch.resize((size_t)2 * n);
+        const uint32_t root = 2u * n - 2u;      // split positions are 1 .. n - 1: entries 0 .. 2n - 3 hold the pairs
+        build(0, n, root, 1);
+        nodes.reserve((size_t)n);
         nodes.assign(2, NodeRec());
         std::memset(nodes.data(), 0, sizeof(NodeRec) * 2);
-        leaf_order.reserve(n);
-        build(0, n, 0, 1);
+        compact(root, 0, 1);
+        std::vector<NodeRec>().swap(scratch);
         // Pad every box: the slab test and the primitive tests round differently, and a ray
         // that a primitive test accepts must never be culled by a box.
         float ext = 0.0f;
@@ -465,7 +551,8 @@ struct WideBuilder {
 };
 
 // primitive record for global surface index `g`
-void emit_prim(const HostScene& in, uint32_t g, uint32_t order, std::vector<q4>& prims)
+// Writes the three words of surface `g` to `prims`.
+void emit_prim(const HostScene& in, uint32_t g, uint32_t order, q4* prims)
 {
     const uint32_t nt = in.n_tris(), ns = in.n_spheres();
     if (g < nt) {
@@ -475,23 +562,23 @@ void emit_prim(const HostScene& in, uint32_t g, uint32_t order, std::vector<q4>&
         float ac[3] = {p[6] - p[0], p[7] - p[1], p[8] - p[2]};
         uint8_t fl = in.tri_flags[g];
         uint32_t info = PRIM_TRI | ((fl & 1u) ? (uint32_t)INFO_FLIP : 0u) | ((fl & 2u) ? (uint32_t)INFO_BLEND : 0u) | (in.tri_mat[g] << 8);
-        prims.push_back(mkq(p[0], p[1], p[2], ab[0]));
-        prims.push_back(mkq(ab[1], ab[2], ac[0], ac[1]));
-        prims.push_back(mkq(ac[2], bitsf(info), bitsf(order), bitsf(g)));
+        prims[0] = mkq(p[0], p[1], p[2], ab[0]);
+        prims[1] = mkq(ab[1], ab[2], ac[0], ac[1]);
+        prims[2] = mkq(ac[2], bitsf(info), bitsf(order), bitsf(g));
     } else if (g < nt + ns) {
         uint32_t i = g - nt;
         const float* s = &in.sph[(size_t)i * 4];
         uint32_t info = PRIM_SPHERE | (in.sph_mat[i] << 8);
-        prims.push_back(mkq(s[0], s[1], s[2], s[3]));
-        prims.push_back(mkq(0, 0, 0, 0));
-        prims.push_back(mkq(0, bitsf(info), bitsf(order), 0));
+        prims[0] = mkq(s[0], s[1], s[2], s[3]);
+        prims[1] = mkq(0, 0, 0, 0);
+        prims[2] = mkq(0, bitsf(info), bitsf(order), 0);
     } else {
         uint32_t i = g - nt - ns;
         const float* r = &in.rect[(size_t)i * 5];
         uint32_t info = PRIM_RECT | (in.rect_mat[i] << 8);
-        prims.push_back(mkq(r[0], r[1], r[2], r[3]));
-        prims.push_back(mkq(r[4], 0, 0, 0));
-        prims.push_back(mkq(0, bitsf(info), bitsf(order), 0));
+        prims[0] = mkq(r[0], r[1], r[2], r[3]);
+        prims[1] = mkq(r[4], 0, 0, 0);
+        prims[2] = mkq(0, bitsf(info), bitsf(order), 0);
     }
 }
 
@@ -654,15 +741,19 @@ int flatten_scene(const HostScene& in, int world_kind, FlatScene& out, std::stri
     }
     out.n_lights = (uint32_t)in.lights.size();
     out.n_materials = nm;
-    out.normals.reserve((size_t)nt * 3);
-    for (uint32_t i = 0; i < nt; i++) {
-        const float* n = &in.tri_nrm[(size_t)i * 9];
-        out.normals.push_back(mkq(n[0], n[1], n[2], 0.0f));
-        out.normals.push_back(mkq(n[3], n[4], n[5], 0.0f));
-        out.normals.push_back(mkq(n[6], n[7], n[8], 0.0f));
-    }
+    out.normals.resize((size_t)nt * 3);
+    parallel_slices(nt, [&](uint32_t first, uint32_t last) {
+        for (uint32_t i = first; i < last; i++) {
+            const float* n = &in.tri_nrm[(size_t)i * 9];
+            q4* dst = &out.normals[(size_t)i * 3];
+            dst[0] = mkq(n[0], n[1], n[2], 0.0f);
+            dst[1] = mkq(n[3], n[4], n[5], 0.0f);
+            dst[2] = mkq(n[6], n[7], n[8], 0.0f);
+        }
+    });
     out.n_prims = (uint32_t)total;
-    out.prims.reserve((size_t)total * 3);
+    out.prims.resize((size_t)total * 3);
+    q4* const prims = out.prims.data();
 
     const uint32_t n_boxed = nt + ns;
     const bool tiny = world_kind == SRT_WORLD_SURFACELIST && n_boxed <= 8;
@@ -672,7 +763,7 @@ int flatten_scene(const HostScene& in, int world_kind, FlatScene& out, std::stri
         if (world_kind == SRT_WORLD_BVHNODE) {
             ReferenceBuilder b(pb);
             b.run();
-            for (uint32_t i = 0; i < b.leaf_order.size(); i++) emit_prim(in, b.leaf_order[i], i, out.prims);
+            for (uint32_t i = 0; i < b.leaf_order.size(); i++) emit_prim(in, b.leaf_order[i], i, prims + (size_t)i * 3);
             emit_nodes(b.nodes, out.nodes);
             out.n_nodes = (uint32_t)b.nodes.size();
             out.bvh_depth = b.max_depth;
@@ -685,7 +776,9 @@ int flatten_scene(const HostScene& in, int world_kind, FlatScene& out, std::stri
         } else {
             SahBuilder b(pb);
             b.run();
-            for (uint32_t i = 0; i < b.leaf_order.size(); i++) emit_prim(in, b.leaf_order[i], b.leaf_order[i], out.prims);
+            parallel_slices((uint32_t)b.leaf_order.size(), [&](uint32_t first, uint32_t last) {
+                for (uint32_t i = first; i < last; i++) emit_prim(in, b.leaf_order[i], b.leaf_order[i], prims + (size_t)i * 3);
+            });
             WideBuilder w(b.nodes);
             w.run();
             out.nodes.swap(w.out);
@@ -696,10 +789,10 @@ int flatten_scene(const HostScene& in, int world_kind, FlatScene& out, std::stri
         if (out.bvh_depth > (uint32_t)STACK_DEPTH) { err = "BVH deeper than the traversal stack"; return SRT_E_LIMIT; }
         out.has_bvh = 1;
         out.list_first = n_boxed;
-        for (uint32_t i = 0; i < nr; i++) emit_prim(in, n_boxed + i, n_boxed + i, out.prims);
+        for (uint32_t i = 0; i < nr; i++) emit_prim(in, n_boxed + i, n_boxed + i, prims + (size_t)(n_boxed + i) * 3);
         out.list_count = nr;
     } else {
-        for (uint32_t g = 0; g < (uint32_t)total; g++) emit_prim(in, g, g, out.prims);
+        for (uint32_t g = 0; g < (uint32_t)total; g++) emit_prim(in, g, g, prims + (size_t)g * 3);
         out.list_first = 0;
         out.list_count = (uint32_t)total;
         out.has_bvh = 0;

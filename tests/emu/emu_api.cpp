@@ -270,6 +270,19 @@ int64_t srt_emu_item_order(srt_ctx* c, const srt_render_params* p, uint32_t scat
     }
     return (int64_t)ra.n_items;
 }
+// FNV-1a over the flattened arrays of the committed scene (nodes, primitives, normals): two builds of one scene
+// give the same digest exactly when they laid out the same tree.
+uint64_t srt_emu_scene_digest(srt_ctx* c)
+{
+    if (!c->committed) return 0;
+    uint64_t h = 1469598103934665603ull;
+    auto eat = [&](const std::vector<q4>& v) {
+        const unsigned char* b = reinterpret_cast<const unsigned char*>(v.data());
+        for (size_t i = 0; i < v.size() * sizeof(q4); i++) { h ^= b[i]; h *= 1099511628211ull; }
+    };
+    eat(c->flat.nodes); eat(c->flat.prims); eat(c->flat.normals);
+    return h;
+}
 int srt_get_stats(srt_ctx* c, srt_stats* out) { *out = c->stats; return SRT_OK; }
 int64_t srt_local_pixels(const srt_render_params* p) { return output_pixels(p); }
 

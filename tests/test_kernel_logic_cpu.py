@@ -104,3 +104,21 @@ def test_item_order_covers_every_pixel_and_sample_once(emu, width, height, sampl
             tx, ty = t % tiles_x, t // tiles_x
             mine += (min(32, width - tx * 32)) * (min(32, height - ty * 32))
         assert len(pairs) == mine * samples
+
+
+def test_threaded_sah_build_lays_out_the_same_tree(emu, monkeypatch):
+    """The SAH builder hands large left halves to other threads and splices the pieces back: the flattened scene
+    (node order, primitive order, boxes) must be byte for byte what one thread builds."""
+    import ctypes as C
+    import helpers
+    digest = emu._lib.srt_emu_scene_digest
+    digest.restype = C.c_uint64
+    world, lights, cam = helpers.mesh_spec(n=40).host(64, 36)       # 6,400 + 72 triangles, 3 spheres
+    seen = {}
+    for fork_min in ("0", "101", "500", "3000"):
+        monkeypatch.setenv("SRT_BUILD_FORK_MIN", fork_min)
+        emu.set_scene(world, lights, cam, world_kind=srt.WORLD_SURFACELIST)
+        st = emu.stats()
+        seen[fork_min] = (digest(emu._ctx), st["bvh_nodes"], st["bvh_depth"], st["n_prims"])
+    assert seen["0"][0] != 0
+    assert len(set(seen.values())) == 1, seen

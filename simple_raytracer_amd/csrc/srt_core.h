@@ -316,6 +316,38 @@ SRT_HD void test_prim(const SceneView& sc, uint32_t idx, f3 o, f3 d, float a, fl
     }
 }
 
+// SurfaceList.hit (RaytracingClasses.cs:296-316) over every surface of the world, for the queries of a
+// SurfaceList world that the library's own tree must not answer.  The reference scans the list in order, handing
+// each surface the closest t so far as its upper bound, and a surface test can report a hit at t = NaN (every
+// rejection in Tri.hit / Sphere.hit / RectAxis.hit is a comparison, and all of them are false for a NaN): that hit
+// is accepted whatever came before it, and the surface after it is accepted whatever its distance.  So the scan
+// returns the closest hit among the surfaces AFTER the last NaN hit (or that NaN hit, if none follows); with no NaN
+// hit that is the closest hit overall, which is what the tree computes in any order.  NaN distances need an
+// overflow or 0 * inf inside a test.  The tree is only built over surfaces whose coordinates stay below
+// kTameRange (the triple products of a test then stay finite), and it only answers rays that start inside that
+// range, with a direction of ordinary length, after the surfaces outside the tree reported no NaN hit; every other
+// query comes here: two passes over the surfaces in memory order, the first finds the last NaN hit in list order.
+constexpr float kTameRange = 0x1p40f;
+template <bool COUNT>
+SRT_HD Hit scan_all_surfaces(const SceneView& sc, f3 o, f3 d, float a, float t_min, Counters& cnt)
+{
+    Hit none;
+    none.t = INFINITY; none.prim = NO_PRIM; none.u = 0.0f; none.v = 0.0f; none.order = 0u;
+    Hit best = none;
+    for (uint32_t i = 0; i < sc.n_prims; i++) {
+        Hit h = none;
+        test_prim<COUNT>(sc, i, o, d, a, t_min, h, cnt);
+        if (h.prim != NO_PRIM && h.t != h.t && (best.prim == NO_PRIM || h.order >= best.order)) best = h;
+    }
+    const bool after = best.prim != NO_PRIM;
+    const uint32_t last_nan = best.order;
+    for (uint32_t i = 0; i < sc.n_prims; i++) {
+        if (after && fbits(sc.prims[3 * i + 2].z) <= last_nan) continue;
+        test_prim<COUNT>(sc, i, o, d, a, t_min, best, cnt);
+    }
+    return best;
+}
+
 // ------------------------------------------------------------------------------------------
 // Box tests
 // ------------------------------------------------------------------------------------------
@@ -443,7 +475,17 @@ SRT_HD void trav_begin(const SceneView& sc, f3 o, float t_min, Trav& tr, uint32_
     best.t = INFINITY; best.prim = NO_PRIM; best.u = 0.0f; best.v = 0.0f; best.order = 0u;
     const f3 d = tr.d;
     const float a = lensq3(d);
-    for (uint32_t i = 0; i < sc.list_count; i++) test_prim<COUNT>(sc, sc.list_first + i, o, d, a, t_min, best, cnt);
+    bool plain = true;
+    if (!EXACT) plain = (fabsf(o.x) <= kTameRange) & (fabsf(o.y) <= kTameRange) & (fabsf(o.z) <= kTameRange) & (a <= 4.0f);  // false for NaN
+    for (uint32_t i = 0; i < sc.list_count; i++) {
+        test_prim<COUNT>(sc, sc.list_first + i, o, d, a, t_min, best, cnt);
+        if (!EXACT) plain = plain & (best.t == best.t);
+    }
+    if (!plain) {
+        tr.best = scan_all_surfaces<COUNT>(sc, o, d, a, t_min, cnt);
+        tr.cur = TRAV_NONE;
+        return;
+    }
     tr.best = best;
     if (EXACT) {
         const f3 inv = mk3(1.0f / d.x, 1.0f / d.y, 1.0f / d.z);

@@ -379,15 +379,18 @@ struct SahBuilder {
             compact(nd.desc + 1, pair + 1, depth + 1);
         }
     }
-    void run()
+    // `members`: the primitives (indices into the boxes) the tree is built over, at least one
+    void run(std::vector<uint32_t> members)
     {
-        const uint32_t n = (uint32_t)pb.size();
-        ids.resize(n);
-        for (int k = 0; k < 3; k++) cx[k].resize(n);
-        for (uint32_t i = 0; i < n; i++) {
-            ids[i] = i;
-            for (int k = 0; k < 3; k++) cx[k][i] = 0.5f * pb[i].mn[k] + 0.5f * pb[i].mx[k];
-        }
+        ids.swap(members);
+        const uint32_t n = (uint32_t)ids.size();
+        for (int k = 0; k < 3; k++) cx[k].resize(pb.size());
+        parallel_slices(n, [&](uint32_t first, uint32_t last) {
+            for (uint32_t i = first; i < last; i++) {
+                const uint32_t id = ids[i];
+                for (int k = 0; k < 3; k++) cx[k][id] = 0.5f * pb[id].mn[k] + 0.5f * pb[id].mx[k];
+            }
+        });
         // at most 2 * FORK_SHARE - 1 nodes hold n / FORK_SHARE primitives or more: that bounds the threads
         fork_min = std::max<uint32_t>(FORK_FLOOR, n / FORK_SHARE);
         if (const char* e = std::getenv("SRT_BUILD_FORK_MIN")) {
@@ -757,9 +760,24 @@ int flatten_scene(const HostScene& in, int world_kind, FlatScene& out, std::stri
 
     const uint32_t n_boxed = nt + ns;
     const bool tiny = world_kind == SRT_WORLD_SURFACELIST && n_boxed <= 8;
+    std::vector<Box> pb;
+    std::vector<uint32_t> members, strays;
+    uint32_t n_tree = n_boxed;
     if (n_boxed > 0 && !tiny) {
-        std::vector<Box> pb;
         primitive_boxes(in, pb);
+        if (world_kind == SRT_WORLD_SURFACELIST) {
+            // The library's own tree only holds surfaces whose tests stay inside float range (see
+            // scan_all_surfaces in srt_core.h); the others are scanned linearly, like the rects.
+            members.reserve(n_boxed);
+            for (uint32_t i = 0; i < n_boxed; i++) {
+                bool tame = true;
+                for (int k = 0; k < 3; k++)
+                    tame = tame && std::fabs(pb[i].mn[k]) <= kTameRange && std::fabs(pb[i].mx[k]) <= kTameRange;   // false for NaN
+                (tame ? members : strays).push_back(i);
+            }
+        }
+    }
+    if (n_boxed > 0 && !tiny && (world_kind == SRT_WORLD_BVHNODE || !members.empty())) {
         if (world_kind == SRT_WORLD_BVHNODE) {
             ReferenceBuilder b(pb);
             b.run();
@@ -775,10 +793,11 @@ int flatten_scene(const HostScene& in, int world_kind, FlatScene& out, std::stri
             }
         } else {
             SahBuilder b(pb);
-            b.run();
+            b.run(std::move(members));
             parallel_slices((uint32_t)b.leaf_order.size(), [&](uint32_t first, uint32_t last) {
                 for (uint32_t i = first; i < last; i++) emit_prim(in, b.leaf_order[i], b.leaf_order[i], prims + (size_t)i * 3);
             });
+            n_tree = (uint32_t)b.leaf_order.size();
             WideBuilder w(b.nodes);
             w.run();
             out.nodes.swap(w.out);
@@ -788,9 +807,11 @@ int flatten_scene(const HostScene& in, int world_kind, FlatScene& out, std::stri
         }
         if (out.bvh_depth > (uint32_t)STACK_DEPTH) { err = "BVH deeper than the traversal stack"; return SRT_E_LIMIT; }
         out.has_bvh = 1;
-        out.list_first = n_boxed;
+        // scanned linearly after the tree: the surfaces kept out of it, then the rects
+        out.list_first = n_tree;
+        for (uint32_t i = 0; i < (uint32_t)strays.size(); i++) emit_prim(in, strays[i], strays[i], prims + (size_t)(n_tree + i) * 3);
         for (uint32_t i = 0; i < nr; i++) emit_prim(in, n_boxed + i, n_boxed + i, prims + (size_t)(n_boxed + i) * 3);
-        out.list_count = nr;
+        out.list_count = (uint32_t)strays.size() + nr;
     } else {
         for (uint32_t g = 0; g < (uint32_t)total; g++) emit_prim(in, g, g, prims + (size_t)g * 3);
         out.list_first = 0;

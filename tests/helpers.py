@@ -186,6 +186,32 @@ def mesh_spec(kind="sphere", n=16, with_spheres=True, with_rect=False):
     return s
 
 
+def stray_spec(kind):
+    """300 random triangles and a sphere, plus surfaces whose coordinates leave the range in which a surface test
+    stays finite: NaN or infinite vertices, or a triangle 1e20 / 3e38 across.  The reference's tests then report
+    hits at t = NaN, which its list scan accepts whatever came before; a SurfaceList world has to reproduce that
+    scan, not the geometry."""
+    rng = np.random.default_rng(1)
+    base = (rng.normal(0, 3, (300, 9)) + np.array([0, 0, -8] * 3)).astype(np.float32)
+    sign = np.array([1, 1, 1, -1, 1, 1, 1, -1, 1], np.float32)
+    extra = {
+        "nan": np.full((3, 9), np.nan, np.float32),
+        "one-nan": np.array([[np.nan, 0, -5, 1, 0, -5, 0, 1, -5]], np.float32),
+        "inf": np.full((2, 9), np.inf, np.float32),
+        "3e38": np.full((1, 9), 3e38, np.float32) * sign,
+        "1e20": np.full((1, 9), 1e20, np.float32) * sign,
+        "1e20-first": np.full((1, 9), 1e20, np.float32) * sign,
+    }[kind]
+    pos = np.concatenate([extra, base] if kind.endswith("first") else [base[:150], extra, base[150:]])
+    s = SceneSpec()
+    s.materials = [((0.8, 0.5, 0.5), 0.0, 0.5, (0, 0, 0)), ((0.6, 0.7, 0.9), 0.5, 0.8, (0, 0, 0))]
+    s.meshes.append((pos, np.tile(np.array([[0, 0, 1] * 3], np.float32), (len(pos), 1)), 0, False, True))
+    s.spheres = [((0.0, 0.0, -5.0), 1.0, 1)]
+    s.lights = [((4.0, -3.0, 1.0), 5.0, None)]
+    s.camera = ((0, 0, 0), (0.0, 0.0, -6.0), 55)
+    return s
+
+
 def teapot_spec():
     """The reference's teapot.dae (6,320 triangles, from the committed fixture) with mat6 (Game1.cs:109), the loader's
     fallback camera Camera((0,0,6), (0,0,0), 29) (ModelLoader.cs:105) and the two Game1 lights (Game1.cs:140-141)."""

@@ -48,6 +48,16 @@ CASES = [
     ("glossy-depth6-list", helpers.glossy_spec, 48, 27, 2, 6, COLOR, LIST, 11),
     ("many-materials-bvhnode", helpers.many_materials_spec, 96, 54, 2, 5, COLOR, BVH, 4),
     ("many-materials-list", helpers.many_materials_spec, 96, 54, 2, 5, COLOR, LIST, 4),
+    # surfaces outside the range in which the surface tests stay finite (hits at t = NaN, rays that start 1e20 away)
+    ("stray-nan-list", lambda: helpers.stray_spec("nan"), 48, 27, 1, 3, COLOR, LIST, 2),
+    ("stray-one-nan-list", lambda: helpers.stray_spec("one-nan"), 48, 27, 1, 3, COLOR, LIST, 2),
+    ("stray-inf-list", lambda: helpers.stray_spec("inf"), 48, 27, 1, 3, COLOR, LIST, 2),
+    ("stray-3e38-list", lambda: helpers.stray_spec("3e38"), 48, 27, 1, 3, COLOR, LIST, 2),
+    ("stray-1e20-list", lambda: helpers.stray_spec("1e20"), 48, 27, 2, 4, COLOR, LIST, 2),
+    ("stray-1e20-normal-list", lambda: helpers.stray_spec("1e20"), 48, 27, 1, 3, NORMAL, LIST, 2),
+    ("stray-1e20-first-list", lambda: helpers.stray_spec("1e20-first"), 48, 27, 1, 3, COLOR, LIST, 5),
+    ("stray-1e20-bvhnode", lambda: helpers.stray_spec("1e20"), 48, 27, 1, 3, COLOR, BVH, 2),
+    ("stray-nan-bvhnode", lambda: helpers.stray_spec("nan"), 48, 27, 1, 3, COLOR, BVH, 2),
 ]
 
 

@@ -774,6 +774,10 @@ int flatten_scene(const HostScene& in, int world_kind, FlatScene& out, std::stri
                 for (int k = 0; k < 3; k++)
                     tame = tame && std::fabs(pb[i].mn[k]) <= kTameRange && std::fabs(pb[i].mx[k]) <= kTameRange;   // false for NaN
                 (tame ? members : strays).push_back(i);
+                // Sphere.boundingBox of a negative radius has its corners the wrong way round; the reference's
+                // own tree keeps it so, this one needs the box the sphere fills
+                for (int k = 0; k < 3; k++)
+                    if (pb[i].mn[k] > pb[i].mx[k]) std::swap(pb[i].mn[k], pb[i].mx[k]);
             }
         }
     }

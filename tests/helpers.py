@@ -212,6 +212,45 @@ def stray_spec(kind):
     return s
 
 
+def nasty_spec(seed):
+    """Random small scenes made of the inputs a model file can hold and a tree builder trips over: zero-length
+    edges, collinear and duplicated triangles, vertices on a lattice (equal hit distances), coplanar triangles,
+    spheres of radius 0, of negative radius (Sphere.boundingBox then has its corners the wrong way round), spheres
+    the camera is inside of, concentric spheres, a rect through the camera plane."""
+    rng = np.random.default_rng(seed)
+    s = SceneSpec()
+    s.materials = [((0.8, 0.5, 0.5), 0.0, 0.5, (0, 0, 0)), ((0.6, 0.7, 0.9), 0.7, 0.9, (0, 0, 0)), ((0.9, 0.9, 0.2), 1.0, 0.3, (0.5, 0.5, 0))]
+    nt = int(rng.integers(0, 60))
+    pos = (rng.normal(0, 2.5, (nt, 9)) + np.array([0, 0, -7] * 3)).astype(np.float32)
+    for i in range(nt):
+        k = rng.integers(0, 12)
+        if k == 0:
+            pos[i, 3:6] = pos[i, 0:3]
+        elif k == 1:
+            pos[i, 6:9] = pos[i, 0:3] + 2 * (pos[i, 3:6] - pos[i, 0:3])
+        elif k == 2 and i > 0:
+            pos[i] = pos[i - 1]
+        elif k == 3:
+            pos[i] = np.round(pos[i])
+        elif k == 4:
+            pos[i, 2::3] = -6.0
+    if nt:
+        nrm = np.tile(np.array([[0, 0, 1] * 3], np.float32), (nt, 1))
+        s.meshes.append((pos, nrm, int(rng.integers(0, 3)), bool(rng.integers(0, 2)), bool(rng.integers(0, 2))))
+    s.spheres = []
+    for i in range(int(rng.integers(0, 14))):
+        c = tuple(float(v) for v in (rng.normal(0, 2.5, 3) + np.array([0, 0, -7])).astype(np.float32))
+        rad = float(np.float32(rng.choice([0.0, -0.8, 0.5, 1.0, 1e-3, 30.0, 1.0, 0.7])))
+        if i > 0 and rng.integers(0, 5) == 0:
+            c = s.spheres[-1][0]
+        s.spheres.append((c, rad, int(rng.integers(0, 3))))
+    if rng.integers(0, 3) == 0:
+        s.rects = [(-3, 3, -3, 1, float(rng.choice([9.0, 6.0, 0.0])), 1)]
+    s.lights = [((4.0, -3.0, 1.0), 5.0, None), ((0.0, 0.0, -7.0), 2.0, (1.0, 0.5, 0.5))]
+    s.camera = ((0, 0, 0), (0.0, 0.0, -6.0), 55) if rng.integers(0, 2) else ((0.1, 0.2, -6.5), (0.3, 0.1, -9.0), 80)
+    return s
+
+
 def teapot_spec():
     """The reference's teapot.dae (6,320 triangles, from the committed fixture) with mat6 (Game1.cs:109), the loader's
     fallback camera Camera((0,0,6), (0,0,0), 29) (ModelLoader.cs:105) and the two Game1 lights (Game1.cs:140-141)."""

@@ -59,6 +59,12 @@ CASES = [
     ("stray-1e20-bvhnode", lambda: helpers.stray_spec("1e20"), 48, 27, 1, 3, COLOR, BVH, 2),
     ("stray-nan-bvhnode", lambda: helpers.stray_spec("nan"), 48, 27, 1, 3, COLOR, BVH, 2),
 ]
+# degenerate surfaces (see helpers.nasty_spec); seeds 36, 44, 50, 56, 68, 77 hold spheres of negative radius
+for _seed in (3, 36, 44, 50, 56, 68, 77, 101, 102, 103):
+    _spec = helpers.nasty_spec(_seed)
+    CASES.append(("nasty-%d-list" % _seed, (lambda sp=_spec: sp), 40, 24, 1, 4, COLOR, LIST, _seed))
+    if not _spec.rects:
+        CASES.append(("nasty-%d-bvhnode" % _seed, (lambda sp=_spec: sp), 40, 24, 1, 4, COLOR, BVH, _seed))
 
 
 def clamp_for(name):

@@ -154,3 +154,27 @@ def test_gpu_passes_and_degenerate_pictures(gpu_filters, oracle):
     # the mirror of the reference's class: same names, one pass per call
     s = srt.Sorting(gpu_filters)
     assert (s.Despeckle(img.ravel(), 70, 90, 1.0, 200.0).reshape(90, 70) == oracle.Despeckle(img, 1.0, 200.0)).all()
+
+
+ODD_PARAMETERS = [("blur_array", "BlurArray", (float("nan"),)), ("blur_array", "BlurArray", (-2.0,)), ("blur_array", "BlurArray", (7.5,)),
+                  ("despeckle", "Despeckle", (1.0, float("nan"))), ("despeckle", "Despeckle", (float("inf"), 10.0)),
+                  ("contrast_blur_array", "ContrastBlurArray", (float("inf"), -3.0)), ("contrast_blur_array", "ContrastBlurArray", (0.5, float("nan")))]
+
+
+def check_odd_parameters(filters, oracle):
+    """Weights and thresholds outside their ranges, NaN and infinite included, on small and ragged pictures: the
+    float -> byte conversions of the recurrence have to saturate and truncate as the reference's casts do."""
+    for h, w in ((3, 3), (4, 3), (3, 129), (129, 3), (40, 33)):
+        img = random_image(h, w, 31 * h + w)
+        for name, oracle_name, args in ODD_PARAMETERS:
+            got = getattr(filters, name)(img, *args)
+            assert (got == getattr(oracle, oracle_name)(img, *args)).all(), (h, w, name, args)
+
+
+def test_kernel_source_takes_odd_parameters(emu_lib, oracle):
+    check_odd_parameters(srt.Renderer(library=emu_lib, strict=False), oracle)
+
+
+@pytest.mark.gpu
+def test_gpu_takes_odd_parameters(gpu_filters, oracle):
+    check_odd_parameters(gpu_filters, oracle)

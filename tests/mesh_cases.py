@@ -47,3 +47,29 @@ def run(renderer, orc, case, counted=False):
                           world_kind=orc.WORLD_SURFACELIST)
     lsb, npx = helpers.max_lsb_diff(img, ref)
     return lsb, npx, st, ost
+
+
+def large_mesh_window(renderer, orc):
+    """teapot.dae subdivided twice (101,120 triangles) as a SurfaceList world: one 32x8 window at the centre of a
+    640x360 picture through the library's own tree, against the oracle's linear SurfaceList.hit scan.
+    -> (max LSB difference, differing pixels, distinct colours in the window, tree nodes)."""
+    from simple_raytracer_amd import scenes
+    w, h, depth = 640, 360, 4
+    world, lights, cam = scenes.teapot_scene(w, h, 2)
+    flat = world.flatten()
+    assert len(flat["tri_pos"]) == 101120
+    mats = [orc.material(m.albedo, m.metalness, m.smoothness, m.emission) for m in flat["materials"]]
+    tris = orc.tris_from_arrays(flat["tri_pos"], flat["tri_nrm"], 0)
+    tris["material"] = flat["tri_mat"]
+    osc = orc.Scene(mats, spheres=[], tris=tris, lights=[orc.point_light(l.position, l.brightness, None) for l in lights.lights])
+    ocam = orc.Camera(orc.f3(cam.position), orc.f3(cam.lowerLeftCorner), orc.f3(cam.horizontal), orc.f3(cam.vertical))
+    tile_x, tile_y = (w // 2) // 32, (h // 2) // 32
+    x0, y0 = tile_x * 32, tile_y * 32
+    ref, _ = osc.render(ocam, w, h, samples=2, max_depth=depth, seed=3, window=(x0, y0, x0 + 32, y0 + 8), world_kind=srt.WORLD_SURFACELIST)
+    renderer.set_scene(world, lights, cam, world_kind=srt.WORLD_SURFACELIST)
+    nodes = renderer.stats()["bvh_nodes"]
+    tiles_x, tiles_y = (w + 31) // 32, (h + 31) // 32
+    tile = renderer.render(w, h, samples=2, max_depth=depth, seed=3, layout=srt.LAYOUT_TILES, tile_w=32, tile_h=32,
+                           rank=tile_y * tiles_x + tile_x, world_size=tiles_x * tiles_y).reshape(32, 32)
+    lsb, npx = helpers.max_lsb_diff(tile[:8, :], ref[y0:y0 + 8, x0:x0 + 32])
+    return lsb, npx, len(np.unique(tile[:8, :])), nodes

@@ -346,3 +346,11 @@ def test_gpu_reproduces_post_golden(gpu):
     n, samples, depth, seed = POST_ARGS["mix"]
     lsb, _ = helpers.max_lsb_diff(gpu.render_mix_buffers(64, 36, n, samples=samples, max_depth=depth, seed=seed), g["mix"])
     assert lsb <= 1
+
+
+
+def test_gpu_thread_built_tree_matches_linear_scan(gpu, oracle):
+    """101,120 triangles: large enough for srt_commit_scene to build the tree on several host threads."""
+    lsb, npx, colours, nodes = mesh_cases.large_mesh_window(gpu, oracle)
+    assert lsb <= 1, "%d LSB over %d pixels" % (lsb, npx)
+    assert colours > 20 and nodes > 10000       # the window shows the teapot, not the sky

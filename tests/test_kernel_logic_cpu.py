@@ -122,3 +122,10 @@ def test_threaded_sah_build_lays_out_the_same_tree(emu, monkeypatch):
         seen[fork_min] = (digest(emu._ctx), st["bvh_nodes"], st["bvh_depth"], st["n_prims"])
     assert seen["0"][0] != 0
     assert len(set(seen.values())) == 1, seen
+
+
+def test_thread_built_tree_of_a_large_mesh_matches_linear_scan(emu, oracle):
+    import mesh_cases
+    lsb, npx, colours, nodes = mesh_cases.large_mesh_window(emu, oracle)
+    assert (lsb, npx) == (0, 0)
+    assert colours > 20 and nodes > 10000

@@ -4,7 +4,12 @@
  * like Game1.Update does every frame (:188-201), and save the frame (:239-244; here a binary PPM instead of a PNG).
  * It shows the call sequence a maintainer's P/Invoke layer makes and needs nothing but include/srt.h.
  *
- *   game1_host [width height samples max_depth seed out.ppm blur_passes]
+ *   game1_host [width height samples max_depth seed out.ppm blur_passes devices]
+ *
+ * devices: how many GPUs share the frame, as Game1 shares it over numberOfAvailableThreads worker threads
+ * (Game1.cs:89-92, 161-167): 0 = one GPU (device 0), N = devices 0..N-1, -1 = every visible GPU, and -N (N >= 2) = N
+ * entries that all name device 0 (the several-device path on a box with a single GPU).  The frame is the same for
+ * every choice.
  */
 #include <math.h>
 #include <stdio.h>
@@ -49,10 +54,24 @@ int main(int argc, char** argv)
     unsigned seed = argc > 5 ? (unsigned)strtoul(argv[5], NULL, 10) : 1u;
     const char* path = argc > 6 ? argv[6] : "game1.ppm";
     int blur_passes = argc > 7 ? atoi(argv[7]) : 0;                                         /* Game1.cs:49: blurPasses = 0 */
+    int devices = argc > 8 ? atoi(argv[8]) : 0;
 
     srt_ctx* ctx = NULL;
-    srt_config cfg = {0, 0};
+    srt_config cfg;
+    memset(&cfg, 0, sizeof cfg);
+    if (devices == -1) cfg.n_devices = SRT_ALL_DEVICES;
+    else if (devices != 0) {
+        int n = devices < 0 ? -devices : devices;
+        if (n > SRT_MAX_DEVICES) { fprintf(stderr, "at most %d devices\n", SRT_MAX_DEVICES); return 1; }
+        cfg.n_devices = n;
+        for (int i = 0; i < n; i++) cfg.devices[i] = devices < 0 ? 0 : i;
+    }
+    cfg.gather = SRT_GATHER_RCCL;
     CHECK(srt_create(&cfg, &ctx));
+    srt_device_info info;
+    CHECK(srt_get_device_info(ctx, &info));
+    fprintf(stderr, "%d device(s), tiles gathered by %s%s\n", info.n_devices, info.n_devices == 1 ? "nobody" : (info.gather == SRT_GATHER_RCCL ? "RCCL" : "peer copies"),
+            info.rccl_ranks ? " (communicator made)" : "");
 
     /* Game1.cs:102-109 */
     srt_material mats[6] = {

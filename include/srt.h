@@ -12,8 +12,8 @@
  *    (SRT_OK) or a negative SRT_E_* code, and srt_last_error() describes the last failure;
  *  - pointers passed in are caller-owned and only read during the call (scene arrays are
  *    copied); output buffers are caller-owned;
- *  - a context is bound to one HIP device and is not thread-safe: the caller serialises
- *    calls, as the single UI thread of Game1 does;
+ *  - a context owns one HIP device or a list of them (srt_config) and is not thread-safe: the
+ *    caller serialises calls, as the single UI thread of Game1 does;
  *  - there is no CPU fallback: without a usable gfx950 device srt_create fails.
  */
 #ifndef SRT_H
@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define SRT_VERSION 100
+#define SRT_VERSION 200
 
 enum {
     SRT_OK = 0,
@@ -77,10 +77,39 @@ typedef struct { float albedo[3]; float metalness; float smoothness; float emiss
 /* PointLight after its constructor ran (brightness possibly rescaled), RaytracingClasses.cs:75-94,190-192. 28 bytes. */
 typedef struct { float position[3]; float brightness; float color[3]; } srt_point_light;
 
+/* How the devices of a context hand their screen tiles to the first device of the list. */
+enum {
+    SRT_GATHER_RCCL = 0,      /* grouped ncclSend / ncclRecv over a communicator made by ncclCommInitAll (the default) */
+    SRT_GATHER_PEER_COPY = 1  /* hipMemcpyPeerAsync from every device into the first one's buffer */
+};
+#define SRT_MAX_DEVICES 8     /* one node */
+#define SRT_ALL_DEVICES (-1)  /* srt_config.n_devices: every visible device */
+
+/* The devices of a context.  The reference fans one render out over Environment.ProcessorCount threads inside one
+ * process (Game1.cs:89-92, 161-167); a context fans it out over the listed GPUs the same way, inside the library:
+ * every device holds the whole scene, traces the 32x32 screen tiles t with t % n_devices == its position in the list,
+ * and hands them to the first device, which assembles the frame.
+ *   n_devices == 0                    one device: `device` (callers that only know the first two fields keep working)
+ *   n_devices == SRT_ALL_DEVICES      every visible device, in ordinal order
+ *   n_devices 1..SRT_MAX_DEVICES      devices[0..n_devices).  An ordinal may be listed more than once: the entries then
+ *                                     share that GPU (a way to run the multi-device path on a box with one GPU), and
+ *                                     the tiles travel by device-to-device copies, since RCCL refuses duplicate devices. */
 typedef struct {
-    int32_t device;          /* HIP device ordinal */
-    int32_t reserved;
+    int32_t device;
+    int32_t n_devices;
+    int32_t devices[SRT_MAX_DEVICES];
+    int32_t gather;           /* SRT_GATHER_* */
+    int32_t reserved[5];      /* zero */
 } srt_config;
+
+/* What srt_create made of the configuration. */
+typedef struct {
+    int32_t n_devices;
+    int32_t devices[SRT_MAX_DEVICES];   /* HIP ordinals, in list order; the first one assembles the frame */
+    int32_t gather;           /* SRT_GATHER_* in use (peer copies when an ordinal is listed twice or RCCL is not needed) */
+    int32_t rccl_ranks;       /* ncclCommCount of the communicator, 0 when none was made (one device, peer copies) */
+    int32_t reserved[5];
+} srt_device_info;
 
 /* Render settings: the hard-coded fields of Game1 (Game1.cs:41-43,78-79) plus the RNG seed
  * (the reference seeds System.Random from entropy, Game1.cs:44,378) and the multi-GPU
@@ -128,9 +157,12 @@ typedef struct srt_ctx srt_ctx;
 
 int  srt_version(void);
 
-/* Replaces nothing in the reference: owns the device-side copies of what Game1 keeps on the heap. */
+/* Replaces nothing in the reference: owns the device-side copies of what Game1 keeps on the heap, one replica per
+ * device of the configuration (NULL = device 0). */
 int  srt_create(const srt_config* cfg, srt_ctx** out);
 void srt_destroy(srt_ctx* ctx);
+/* The devices a context runs on (numberOfAvailableThreads of Game1.cs:89-92, for GPUs). */
+int  srt_get_device_info(const srt_ctx* ctx, srt_device_info* out);
 /* Thread-local text of the last error of `ctx` (or of srt_create when ctx is NULL). */
 const char* srt_last_error(const srt_ctx* ctx);
 
@@ -157,7 +189,12 @@ int  srt_commit_scene(srt_ctx* ctx, int world_kind);
 /* Replaces Parallel.For(0, N, startThread) + renderBlock + WritePixel (Game1.cs:165, 264-317;
  * PixelManagement.cs:8-23).  Blocking; rgba_out is the Color[] buffer (packed R | G<<8 | B<<16 | A<<24)
  * sized for the layout: width*height pixels for SRT_LAYOUT_FRAME, srt_local_pixels() for SRT_LAYOUT_TILES.
- * All rows are rendered (the reference leaves the last height mod N rows black, Game1.cs:378). */
+ * All rows are rendered (the reference leaves the last height mod N rows black, Game1.cs:378).
+ * A context with several devices splits the frame itself (SRT_LAYOUT_FRAME with world_size <= 1; tile_w / tile_h
+ * choose the tile, 0 = 32): each device traces its tiles, the tiles are gathered on the first device, a kernel puts
+ * them into the row-major frame and one copy brings it to rgba_out.  The picture does not depend on the number of
+ * devices.  srt_render, srt_render_counted, srt_render_async / srt_poll / srt_wait and srt_get_stats work that way;
+ * every other entry point of such a context runs on its first device alone. */
 int  srt_render(srt_ctx* ctx, const srt_render_params* p, uint32_t* rgba_out);
 /* Same, writing to device memory on the caller's HIP stream (hipStream_t passed as void*; NULL is HIP's
  * default stream) without synchronising: the host side of a multi-GPU job keeps the tiles on the device
@@ -203,8 +240,11 @@ int  srt_contrast_blur_array(srt_ctx* ctx, uint32_t* array, int32_t width, int32
 int  srt_despeckle(srt_ctx* ctx, uint32_t* array, int32_t width, int32_t height, float weight, float threshold, int32_t passes);
 
 /* Counters of the renders since the previous collection (a blocking render collects, so after srt_render
- * these are that render's counters).  Waits for the most recent launch. */
+ * these are that render's counters).  Waits for the most recent launch.  With several devices the counts are
+ * sums and kernel_ms is the longest device's; srt_get_device_stats gives one device's share (index = position in
+ * the device list) of what srt_get_stats last collected. */
 int  srt_get_stats(srt_ctx* ctx, srt_stats* out);
+int  srt_get_device_stats(srt_ctx* ctx, int32_t index, srt_stats* out);
 
 /* Size in pixels of the buffer a rank renders into for these parameters (tile-major, padded tiles). */
 int64_t srt_local_pixels(const srt_render_params* p);

@@ -31,8 +31,18 @@ class PointLight(C.Structure):
     _fields_ = [("position", C.c_float * 3), ("brightness", C.c_float), ("color", C.c_float * 3)]
 
 
+GATHER_RCCL, GATHER_PEER_COPY = 0, 1
+MAX_DEVICES, ALL_DEVICES = 8, -1
+
+
 class Config(C.Structure):
-    _fields_ = [("device", C.c_int32), ("reserved", C.c_int32)]
+    _fields_ = [("device", C.c_int32), ("n_devices", C.c_int32), ("devices", C.c_int32 * MAX_DEVICES), ("gather", C.c_int32),
+                ("reserved", C.c_int32 * 5)]
+
+
+class DeviceInfo(C.Structure):
+    _fields_ = [("n_devices", C.c_int32), ("devices", C.c_int32 * MAX_DEVICES), ("gather", C.c_int32), ("rccl_ranks", C.c_int32),
+                ("reserved", C.c_int32 * 5)]
 
 
 class RenderParams(C.Structure):
@@ -59,6 +69,7 @@ SYMBOLS = [
     ("srt_create", C.c_int, [C.POINTER(Config), C.POINTER(_CTX)]),
     ("srt_destroy", None, [_CTX]),
     ("srt_last_error", C.c_char_p, [_CTX]),
+    ("srt_get_device_info", C.c_int, [_CTX, C.POINTER(DeviceInfo)]),
     ("srt_set_camera", C.c_int, [_CTX, _FP, _FP, _FP, _FP]),
     ("srt_set_materials", C.c_int, [_CTX, C.POINTER(Material), C.c_uint32]),
     ("srt_set_spheres", C.c_int, [_CTX, _FP, _FP, _FP, _FP, _UP, C.c_uint32]),
@@ -80,6 +91,7 @@ SYMBOLS = [
     ("srt_contrast_blur_array", C.c_int, [_CTX, C.c_void_p, C.c_int32, C.c_int32, C.c_float, C.c_float, C.c_int32]),
     ("srt_despeckle", C.c_int, [_CTX, C.c_void_p, C.c_int32, C.c_int32, C.c_float, C.c_float, C.c_int32]),
     ("srt_get_stats", C.c_int, [_CTX, C.POINTER(Stats)]),
+    ("srt_get_device_stats", C.c_int, [_CTX, C.c_int32, C.POINTER(Stats)]),
     ("srt_local_pixels", C.c_int64, [C.POINTER(RenderParams)]),
     ("srt_assemble_tiles", C.c_int, [_CTX, C.POINTER(RenderParams), C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p]),
 ]

@@ -2,7 +2,15 @@
 //
 // There is no CPU path here: every render goes through launch_trace() on a gfx950 device, and
 // srt_create fails when there is none.
+//
+// A context owns one DeviceState per device of its configuration: a replica of the scene, a stream, the sample
+// buffer and the counters.  A context with one device runs everything there.  A context with several devices
+// splits a frame into screen tiles (srt_multi.h), traces them on all devices at once, gathers the tile buffers on
+// the first device -- grouped ncclSend / ncclRecv over xGMI, or peer copies -- and assembles the frame there.
 #include <hip/hip_runtime_api.h>
+#include <rccl/rccl.h>
+
+#include <dlfcn.h>
 
 #include <chrono>
 #include <cstdlib>
@@ -13,35 +21,99 @@
 
 #include "../../include/srt.h"
 #include "srt_launch.h"
+#include "srt_multi.h"
 #include "srt_scene.h"
 
 using namespace srt;
 
-struct srt_ctx {
-    int device = 0;
+namespace {
+
+// RCCL is bound at run time, and only by contexts that gather with it: a process that renders on one GPU never
+// loads it, and a process that already holds a copy (PyTorch ships one) keeps using that copy.
+struct RcclApi {
+    void* handle = nullptr;
+    ncclResult_t (*CommInitAll)(ncclComm_t*, int, const int*) = nullptr;
+    ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
+    ncclResult_t (*CommCount)(const ncclComm_t, int*) = nullptr;
+    ncclResult_t (*GroupStart)() = nullptr;
+    ncclResult_t (*GroupEnd)() = nullptr;
+    ncclResult_t (*Send)(const void*, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t) = nullptr;
+    ncclResult_t (*Recv)(void*, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t) = nullptr;
+    const char* (*GetErrorString)(ncclResult_t) = nullptr;
+
+    bool load(std::string& err)
+    {
+        if (handle) return true;
+        const char* names[] = {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"};
+        for (const char* n : names) {
+            handle = dlopen(n, RTLD_NOW | RTLD_LOCAL);
+            if (handle) break;
+        }
+        if (!handle) { err = std::string("librccl could not be loaded: ") + dlerror(); return false; }
+        bool ok = true;
+        auto sym = [&](const char* name) { void* p = dlsym(handle, name); if (!p) { ok = false; err = std::string("librccl lacks ") + name; } return p; };
+        CommInitAll = reinterpret_cast<decltype(CommInitAll)>(sym("ncclCommInitAll"));
+        CommDestroy = reinterpret_cast<decltype(CommDestroy)>(sym("ncclCommDestroy"));
+        CommCount = reinterpret_cast<decltype(CommCount)>(sym("ncclCommCount"));
+        GroupStart = reinterpret_cast<decltype(GroupStart)>(sym("ncclGroupStart"));
+        GroupEnd = reinterpret_cast<decltype(GroupEnd)>(sym("ncclGroupEnd"));
+        Send = reinterpret_cast<decltype(Send)>(sym("ncclSend"));
+        Recv = reinterpret_cast<decltype(Recv)>(sym("ncclRecv"));
+        GetErrorString = reinterpret_cast<decltype(GetErrorString)>(sym("ncclGetErrorString"));
+        return ok;
+    }
+};
+RcclApi g_rccl;
+
+// What one device of a context holds.
+struct DeviceState {
+    int device = 0;                       // HIP ordinal
     hipStream_t stream = nullptr;
     hipEvent_t ev_begin = nullptr, ev_end = nullptr;
+    hipEvent_t ev_tiles = nullptr;        // peer-copy gather: this device's tiles have arrived on the first device
+    q4 *d_nodes = nullptr, *d_prims = nullptr, *d_normals = nullptr, *d_materials = nullptr, *d_lights = nullptr, *d_tiny = nullptr;
+    uint32_t* d_out = nullptr;            // the frame (one device) / this device's tile buffer (several)
+    size_t out_capacity = 0;              // pixels
+    unsigned long long* d_stats = nullptr;
+    uint32_t* d_counter = nullptr;        // work counter of the persistent trace kernel
+    float* d_timeline = nullptr;          // scratch of -DSRT_TIMELINE builds (per-wavefront clock records)
+    float* d_samples = nullptr;           // per-(sample, pixel) colours of one pass, 12 bytes each
+    size_t samples_capacity = 0;          // bytes
+    float* d_running = nullptr;           // per-pixel running sums, only for renders that need several passes
+    size_t running_capacity = 0;          // bytes
+    bool stats_pending = false;
+    // The stream of the most recent launch.  The sample buffer, the running sums, the work counter and the two events
+    // are shared by all launches of this device, so a launch on another stream first waits for the previous one.
+    hipStream_t last_stream = nullptr;
+    bool launched = false;
+    srt_stats part{};                     // this device's share of the last collection
+};
+
+}  // namespace
+
+struct srt_ctx {
+    std::vector<DeviceState> dev;         // dev[0] assembles the frame
+    int gather = SRT_GATHER_PEER_COPY;    // how tiles reach dev[0] (several devices)
+    ncclComm_t comms[SRT_MAX_DEVICES] = {};
+    int rccl_ranks = 0;
     HostScene host;
     FlatScene flat;
     bool committed = false;
     int world_kind = SRT_WORLD_BVHNODE;
     Camera cam{};
     bool has_camera = false;
-    q4 *d_nodes = nullptr, *d_prims = nullptr, *d_normals = nullptr, *d_materials = nullptr, *d_lights = nullptr, *d_tiny = nullptr;
-    uint32_t* d_out = nullptr;
-    size_t out_capacity = 0;  // pixels
-    unsigned long long* d_stats = nullptr;
-    uint32_t* d_counter = nullptr;        // work counter of the persistent trace kernel
+    uint64_t sample_budget = (uint64_t)2 << 30;  // bytes the sample buffer of a device may take (SRT_SAMPLE_BUFFER_MB)
+    srt_stats stats{};
+    // dev[0] only
+    uint32_t* d_gathered = nullptr;       // several devices: every device's tile buffer, `stride` pixels apart
+    size_t gathered_capacity = 0;         // pixels
+    uint32_t* d_frame = nullptr;          // several devices: the assembled row-major frame
+    size_t frame_capacity = 0;
     uint32_t* d_mix = nullptr;            // one buffer of the mix-buffer technique
     size_t mix_capacity = 0;              // in pixels
-    float* d_timeline = nullptr;              // scratch of -DSRT_TIMELINE builds (per-wavefront clock records)
-    float* d_samples = nullptr;           // per-(sample, pixel) colours of one pass, 12 bytes each
-    size_t samples_capacity = 0;          // bytes
-    float* d_running = nullptr;           // per-pixel running sums, only for renders that need several passes
-    size_t running_capacity = 0;          // bytes
-    uint64_t sample_budget = (uint64_t)2 << 30;  // bytes the sample buffer may take (SRT_SAMPLE_BUFFER_MB)
-    bool stats_pending = false;
-    srt_stats stats{};
+    uint32_t* d_post[2] = {nullptr, nullptr};   // the picture before / after a pass of a post-process filter
+    size_t post_capacity = 0;             // pixels
+    uint32_t* d_post_progress = nullptr;
     // asynchronous render (srt_render_async / srt_poll / srt_wait)
     uint32_t* h_pinned = nullptr;
     size_t pinned_capacity = 0;
@@ -76,11 +148,16 @@ int hip_fail(srt_ctx* c, hipError_t e, const char* what)
         hipError_t e_ = (call);                                  \
         if (e_ != hipSuccess) return hip_fail((c), e_, #call);   \
     } while (0)
+#define SRT_NCCL(c, call)                                                                                             \
+    do {                                                                                                              \
+        ncclResult_t r_ = (call);                                                                                     \
+        if (r_ != ncclSuccess) return fail((c), SRT_E_HIP, std::string(#call) + ": " + g_rccl.GetErrorString(r_));     \
+    } while (0)
 
-void free_scene_buffers(srt_ctx* c)
+void free_scene_buffers(DeviceState& d)
 {
-    hipFree(c->d_nodes); hipFree(c->d_prims); hipFree(c->d_normals); hipFree(c->d_materials); hipFree(c->d_lights); hipFree(c->d_tiny);
-    c->d_nodes = c->d_prims = c->d_normals = c->d_materials = c->d_lights = c->d_tiny = nullptr;
+    hipFree(d.d_nodes); hipFree(d.d_prims); hipFree(d.d_normals); hipFree(d.d_materials); hipFree(d.d_lights); hipFree(d.d_tiny);
+    d.d_nodes = d.d_prims = d.d_normals = d.d_materials = d.d_lights = d.d_tiny = nullptr;
 }
 
 int upload(srt_ctx* c, const std::vector<q4>& src, q4** dst)
@@ -90,43 +167,90 @@ int upload(srt_ctx* c, const std::vector<q4>& src, q4** dst)
     return SRT_OK;
 }
 
-SceneView scene_view(const srt_ctx* c)
+SceneView scene_view(const srt_ctx* c, const DeviceState& d)
 {
-    return c->flat.view(c->d_nodes, c->d_prims, c->d_normals, c->d_materials, c->d_lights, c->d_tiny);
+    return c->flat.view(d.d_nodes, d.d_prims, d.d_normals, d.d_materials, d.d_lights, d.d_tiny);
 }
 
-// Fetches (and zeroes) the counters accumulated by the launches since the last collection, once
-// the most recent render has finished.  kernel_ms is the device time of that render (all its passes).
-int collect_stats(srt_ctx* c)
+// grows a device buffer of 4-byte pixels (never shrinks); waits for work in flight before it frees the old one
+int ensure_pixels(srt_ctx* c, uint32_t** buf, size_t* capacity, size_t pixels)
 {
-    if (!c->stats_pending) return SRT_OK;
-    SRT_HIP(c, hipEventSynchronize(c->ev_end));
-    unsigned long long s[32];
-    SRT_HIP(c, hipMemcpy(s, c->d_stats, sizeof(s), hipMemcpyDeviceToHost));
-    SRT_HIP(c, hipMemsetAsync(c->d_stats, 0, sizeof(s), c->stream));
-    SRT_HIP(c, hipStreamSynchronize(c->stream));
-#ifdef SRT_TIMELINE
-    if (const char* path = std::getenv("SRT_TIMELINE_FILE")) {
-        std::vector<unsigned long long> tl(4096 * 4);
-        hipMemcpy(tl.data(), reinterpret_cast<char*>(c->d_timeline) + srt::trace_timeline_offset(), tl.size() * 8, hipMemcpyDeviceToHost);
-        if (FILE* f = std::fopen(path, "wb")) { std::fwrite(tl.data(), 8, tl.size(), f); std::fclose(f); }
-    }
-#endif
-    float ms = 0.0f;
-    SRT_HIP(c, hipEventElapsedTime(&ms, c->ev_begin, c->ev_end));
-    c->stats.rays_path = s[0]; c->stats.rays_shadow = s[1]; c->stats.hit_nodes = s[2];
-    c->stats.box_tests = s[3]; c->stats.sphere_tests = s[4]; c->stats.tri_tests = s[5]; c->stats.rect_tests = s[6];
-    c->stats.trace_sections = s[7]; c->stats.trace_lanes = s[8]; c->stats.light_sections = s[9]; c->stats.light_lanes = s[10];
-    for (int i = 0; i < 16; i++) c->stats.section_cycles[i] = s[16 + i];
-    c->stats.kernel_ms = ms;
-    c->stats_pending = false;
-    if (s[11] != 0ull) return fail(c, SRT_E_HIP, "trace kernel: a wavefront gave up waiting for a ray subtree that another lane took over; the picture is incomplete");
+    if (pixels <= *capacity && *buf) return SRT_OK;
+    if (*buf) { SRT_HIP(c, hipDeviceSynchronize()); (void)hipFree(*buf); }
+    *buf = nullptr; *capacity = 0;
+    SRT_HIP(c, hipMalloc((void**)buf, (pixels ? pixels : 1) * sizeof(uint32_t)));
+    *capacity = pixels;
     return SRT_OK;
 }
 
+void zero_counts(srt_stats& s)
+{
+    s.rays_path = s.rays_shadow = s.hit_nodes = 0;
+    s.box_tests = s.sphere_tests = s.tri_tests = s.rect_tests = 0;
+    s.trace_sections = s.trace_lanes = s.light_sections = s.light_lanes = 0;
+    for (int i = 0; i < 16; i++) s.section_cycles[i] = 0;
+    s.kernel_ms = 0.0;
+}
+
+// Fetches (and zeroes) the counters accumulated by the launches since the last collection, once the most recent
+// render of every device has finished.  kernel_ms is the device time of that render (all its passes), the longest
+// one's when several devices took part.
+int collect_stats(srt_ctx* c)
+{
+    bool alarm = false;
+    for (DeviceState& d : c->dev) {
+        if (!d.stats_pending) continue;
+        SRT_HIP(c, hipSetDevice(d.device));
+        SRT_HIP(c, hipEventSynchronize(d.ev_end));
+        unsigned long long s[32];
+        SRT_HIP(c, hipMemcpy(s, d.d_stats, sizeof(s), hipMemcpyDeviceToHost));
+        SRT_HIP(c, hipMemsetAsync(d.d_stats, 0, sizeof(s), d.stream));
+        SRT_HIP(c, hipStreamSynchronize(d.stream));
+#ifdef SRT_TIMELINE
+        if (const char* path = std::getenv("SRT_TIMELINE_FILE")) {
+            std::vector<unsigned long long> tl(srt::trace_timeline_records() * 4);
+            hipMemcpy(tl.data(), reinterpret_cast<char*>(d.d_timeline) + srt::trace_timeline_offset(), tl.size() * 8, hipMemcpyDeviceToHost);
+            if (FILE* f = std::fopen(path, "wb")) { std::fwrite(tl.data(), 8, tl.size(), f); std::fclose(f); }
+        }
+#endif
+        float ms = 0.0f;
+        SRT_HIP(c, hipEventElapsedTime(&ms, d.ev_begin, d.ev_end));
+        srt_stats& p = d.part;
+        p.rays_path = s[0]; p.rays_shadow = s[1]; p.hit_nodes = s[2];
+        p.box_tests = s[3]; p.sphere_tests = s[4]; p.tri_tests = s[5]; p.rect_tests = s[6];
+        p.trace_sections = s[7]; p.trace_lanes = s[8]; p.light_sections = s[9]; p.light_lanes = s[10];
+        for (int i = 0; i < 16; i++) p.section_cycles[i] = s[16 + i];
+        p.kernel_ms = ms;
+        d.stats_pending = false;
+        alarm = alarm || s[11] != 0ull;
+    }
+    zero_counts(c->stats);
+    for (DeviceState& d : c->dev) {
+        const srt_stats& p = d.part;
+        srt_stats& t = c->stats;
+        t.rays_path += p.rays_path; t.rays_shadow += p.rays_shadow; t.hit_nodes += p.hit_nodes;
+        t.box_tests += p.box_tests; t.sphere_tests += p.sphere_tests; t.tri_tests += p.tri_tests; t.rect_tests += p.rect_tests;
+        t.trace_sections += p.trace_sections; t.trace_lanes += p.trace_lanes; t.light_sections += p.light_sections; t.light_lanes += p.light_lanes;
+        for (int i = 0; i < 16; i++) t.section_cycles[i] += p.section_cycles[i];
+        if (p.kernel_ms > t.kernel_ms) t.kernel_ms = p.kernel_ms;
+    }
+    if (alarm) return fail(c, SRT_E_HIP, "trace kernel: a wavefront gave up waiting for a ray subtree that another lane took over; the picture is incomplete");
+    return SRT_OK;
+}
+
+// Memory a launch works in besides the scene and the output.  The usual launch takes it from the device's own
+// buffers, growing them as needed.
+struct Workspace {
+    float* samples = nullptr; size_t samples_bytes = 0;
+    float* running = nullptr; size_t running_bytes = 0;
+    uint32_t* counter = nullptr;
+    bool fixed = false;     // true: never allocate; a render that does not fit is refused
+};
+
 // min_passes > 1 (progressive renders): at least that many passes, each followed by a preview in d_out, a copy of it
 // to pinned memory and an event.
-int launch(srt_ctx* c, const srt_render_params* p, uint32_t* d_out, size_t capacity, hipStream_t stream, bool counted, int min_passes = 1, int mix_buffers = 0)
+int launch(srt_ctx* c, DeviceState& d, const srt_render_params* p, uint32_t* d_out, size_t capacity, hipStream_t stream, bool counted,
+           int min_passes = 1, int mix_buffers = 0, const Workspace* fixed_ws = nullptr)
 {
     if (!c->committed) return fail(c, SRT_E_STATE, "srt_commit_scene has not been called");
     if (!c->has_camera) return fail(c, SRT_E_STATE, "srt_set_camera has not been called");
@@ -136,36 +260,32 @@ int launch(srt_ctx* c, const srt_render_params* p, uint32_t* d_out, size_t capac
     int64_t need = output_pixels(p);
     if (need < 0) return fail(c, (int)need, "bad parameters");
     if ((size_t)need > capacity) return fail(c, SRT_E_INVALID, "output buffer too small for this layout");
-    if (!d_out) return fail(c, SRT_E_INVALID, "output pointer is NULL");
-    SRT_HIP(c, hipSetDevice(c->device));
-    // Samples per pass: as many as fit the sample buffer budget (12 bytes per pixel and sample) and the
-    // 2^31 work-item limit of one launch.
+    if (!d_out && need > 0) return fail(c, SRT_E_INVALID, "output pointer is NULL");
+    SRT_HIP(c, hipSetDevice(d.device));
+    if (&d == &c->dev[0]) c->passes_total = 0;
     if (ra.n_work == 0u) {
         // a rank without tiles: nothing to launch, and the counters of the "render" are all zero
-        c->stats.rays_path = c->stats.rays_shadow = c->stats.hit_nodes = 0;
-        c->stats.box_tests = c->stats.sphere_tests = c->stats.tri_tests = c->stats.rect_tests = 0;
-        c->stats.trace_sections = c->stats.trace_lanes = c->stats.light_sections = c->stats.light_lanes = 0;
-        for (int i = 0; i < 16; i++) c->stats.section_cycles[i] = 0;
-        c->stats.kernel_ms = 0.0f;
+        if (!d.stats_pending) zero_counts(d.part);
         return SRT_OK;
     }
-    uint64_t per_sample = (uint64_t)ra.n_work * 12u;
-    uint64_t fit = c->sample_budget / per_sample;
-    uint64_t by_items = (((uint64_t)1 << 31) - 1) / ra.n_work;
+    // Samples per pass: as many as fit the sample buffer budget (12 bytes per pixel and sample) and the
+    // 2^31 work-item limit of one launch.
+    if ((uint64_t)ra.n_work > (((uint64_t)1 << 31) - 1)) return fail(c, SRT_E_LIMIT, "more than 2^31 pixels per rank");
+    const uint64_t per_sample = (uint64_t)ra.n_work * 12u;
+    const uint64_t budget = fixed_ws ? (uint64_t)fixed_ws->samples_bytes : c->sample_budget;
+    const uint64_t fit = budget / per_sample;
+    const uint64_t by_items = (((uint64_t)1 << 31) - 1) / ra.n_work;
     uint64_t per_pass = fit < by_items ? fit : by_items;
-    if (per_pass < 1) per_pass = 1;
+    if (per_pass < 1) {
+        if (fixed_ws) return fail(c, SRT_E_LIMIT, "the render does not fit the fixed workspace");
+        per_pass = 1;
+    }
     if (per_pass > (uint64_t)ra.samples) per_pass = (uint64_t)ra.samples;
     if (mix_buffers > 0) {
         if (ra.layout != 0 || ra.world_size != 1) return fail(c, SRT_E_INVALID, "the mix-buffer technique renders whole frames (SRT_LAYOUT_FRAME, world_size 1)");
         if ((uint32_t)ra.mode != MODE_COLOR) return fail(c, SRT_E_INVALID, "the mix-buffer technique calls GetRayColor (SRT_MODE_COLOR)");
         per_pass = 1;
-        if ((size_t)need > c->mix_capacity) {
-            SRT_HIP(c, hipDeviceSynchronize());
-            if (c->d_mix) (void)hipFree(c->d_mix);
-            c->d_mix = nullptr; c->mix_capacity = 0;
-            SRT_HIP(c, hipMalloc((void**)&c->d_mix, (size_t)need * sizeof(uint32_t)));
-            c->mix_capacity = (size_t)need;
-        }
+        if ((rc = ensure_pixels(c, &c->d_mix, &c->mix_capacity, (size_t)need)) != SRT_OK) return rc;
     }
     const bool progressive = min_passes > 1;
     if (progressive) {
@@ -175,30 +295,44 @@ int launch(srt_ctx* c, const srt_render_params* p, uint32_t* d_out, size_t capac
         // never more passes than events: later passes grow instead
         uint64_t floor_pp = ((uint64_t)ra.samples + srt_ctx::MAX_PASSES - 1) / srt_ctx::MAX_PASSES;
         if (per_pass < floor_pp) {
-            if (floor_pp * per_sample > c->sample_budget) return fail(c, SRT_E_LIMIT, "a progressive render of this size needs more than 64 passes");
+            if (floor_pp * per_sample > budget || floor_pp > by_items) return fail(c, SRT_E_LIMIT, "a progressive render of this size needs more than 64 passes");
             per_pass = floor_pp;
         }
     }
-    if ((uint64_t)ra.n_work > (((uint64_t)1 << 31) - 1)) return fail(c, SRT_E_LIMIT, "more than 2^31 pixels per rank");
-    size_t need_samples = (size_t)(per_pass * per_sample);
-    if (need_samples > c->samples_capacity) {
-        // (re)allocation waits for work in flight; steady-state renders of one size never get here
-        SRT_HIP(c, hipDeviceSynchronize());
-        if (c->d_samples) hipFree(c->d_samples);
-        c->d_samples = nullptr; c->samples_capacity = 0;
-        SRT_HIP(c, hipMalloc((void**)&c->d_samples, need_samples));
-        c->samples_capacity = need_samples;
-    }
+    const size_t need_samples = (size_t)(per_pass * per_sample);
     const bool multi_pass = per_pass < (uint64_t)ra.samples;
-    if (multi_pass && (size_t)per_sample > c->running_capacity) {
-        SRT_HIP(c, hipDeviceSynchronize());
-        if (c->d_running) hipFree(c->d_running);
-        c->d_running = nullptr; c->running_capacity = 0;
-        SRT_HIP(c, hipMalloc((void**)&c->d_running, (size_t)per_sample));
-        c->running_capacity = (size_t)per_sample;
+    Workspace ws;
+    if (fixed_ws) {
+        ws = *fixed_ws;
+        if (need_samples > ws.samples_bytes || (multi_pass && (size_t)per_sample > ws.running_bytes))
+            return fail(c, SRT_E_LIMIT, "the render does not fit the fixed workspace");
+    } else {
+        if (need_samples > d.samples_capacity) {
+            // (re)allocation waits for work in flight; steady-state renders of one size never get here
+            SRT_HIP(c, hipDeviceSynchronize());
+            if (d.d_samples) hipFree(d.d_samples);
+            d.d_samples = nullptr; d.samples_capacity = 0;
+            SRT_HIP(c, hipMalloc((void**)&d.d_samples, need_samples));
+            d.samples_capacity = need_samples;
+        }
+        if (multi_pass && (size_t)per_sample > d.running_capacity) {
+            SRT_HIP(c, hipDeviceSynchronize());
+            if (d.d_running) hipFree(d.d_running);
+            d.d_running = nullptr; d.running_capacity = 0;
+            SRT_HIP(c, hipMalloc((void**)&d.d_running, (size_t)per_sample));
+            d.running_capacity = (size_t)per_sample;
+        }
+        ws.samples = d.d_samples; ws.samples_bytes = d.samples_capacity;
+        ws.running = d.d_running; ws.running_bytes = d.running_capacity;
+        ws.counter = d.d_counter;
     }
-    SRT_HIP(c, hipEventRecord(c->ev_begin, stream));
-    const SceneView view = scene_view(c);
+    // launches of one device share its workspace, counters and events: one on another stream waits for the last one
+    if (d.launched && d.last_stream != stream) SRT_HIP(c, hipStreamWaitEvent(stream, d.ev_end, 0));
+    d.last_stream = stream;
+    d.launched = true;
+    SRT_HIP(c, hipEventRecord(d.ev_begin, stream));
+    const SceneView view = scene_view(c, d);
+    const bool exact = c->world_kind == SRT_WORLD_BVHNODE;
     if (mix_buffers > 0) {
         // renderBlockFull (Game1.cs:320-374) once per buffer: one sample -- sample index b of the counter RNG stands for
         // thread b's System.Random -- divided by `samples`, gamma, packing; then the pairwise mix of Game1.cs:209-220
@@ -206,16 +340,15 @@ int launch(srt_ctx* c, const srt_render_params* p, uint32_t* d_out, size_t capac
             ra.sample_first = (uint32_t)b;
             ra.sample_count = 1u;
             ra.n_items = ra.n_work;
-            hipError_t e = launch_trace(view, ra, c->world_kind == SRT_WORLD_BVHNODE, counted, c->d_samples, c->d_stats, c->d_counter, c->d_timeline, stream);
+            hipError_t e = launch_trace(view, ra, exact, counted, ws.samples, d.d_stats, ws.counter, d.d_timeline, stream);
             if (e != hipSuccess) return hip_fail(c, e, "trace kernel launch");
-            e = launch_resolve(ra, c->d_samples, c->d_running, c->d_mix, true, true, 0.0f, stream);
+            e = launch_resolve(ra, ws.samples, ws.running, c->d_mix, true, true, 0.0f, stream);
             if (e != hipSuccess) return hip_fail(c, e, "resolve kernel launch");
             e = launch_mix(d_out, c->d_mix, (uint32_t)need, b == 0, stream);
             if (e != hipSuccess) return hip_fail(c, e, "mix kernel launch");
         }
-        c->passes_total = 0;
-        SRT_HIP(c, hipEventRecord(c->ev_end, stream));
-        c->stats_pending = true;
+        SRT_HIP(c, hipEventRecord(d.ev_end, stream));
+        d.stats_pending = true;
         return SRT_OK;
     }
     int pass = 0;
@@ -223,11 +356,11 @@ int launch(srt_ctx* c, const srt_render_params* p, uint32_t* d_out, size_t capac
         ra.sample_first = s0;
         ra.sample_count = (uint32_t)ra.samples - s0 < (uint32_t)per_pass ? (uint32_t)ra.samples - s0 : (uint32_t)per_pass;
         ra.n_items = ra.n_work * ra.sample_count;
-        hipError_t e = launch_trace(view, ra, c->world_kind == SRT_WORLD_BVHNODE, counted, c->d_samples, c->d_stats, c->d_counter, c->d_timeline, stream);
+        hipError_t e = launch_trace(view, ra, exact, counted, ws.samples, d.d_stats, ws.counter, d.d_timeline, stream);
         if (e != hipSuccess) return hip_fail(c, e, "trace kernel launch");
         const uint32_t done = s0 + ra.sample_count;
         const float preview = progressive ? (float)ra.samples / (float)done : 0.0f;
-        e = launch_resolve(ra, c->d_samples, c->d_running, d_out, s0 == 0, done >= (uint32_t)ra.samples, preview, stream);
+        e = launch_resolve(ra, ws.samples, ws.running, d_out, s0 == 0, done >= (uint32_t)ra.samples, preview, stream);
         if (e != hipSuccess) return hip_fail(c, e, "resolve kernel launch");
         if (progressive) {
             SRT_HIP(c, hipMemcpyAsync(c->h_pinned, d_out, (size_t)need * sizeof(uint32_t), hipMemcpyDeviceToHost, stream));
@@ -235,20 +368,85 @@ int launch(srt_ctx* c, const srt_render_params* p, uint32_t* d_out, size_t capac
             SRT_HIP(c, hipEventRecord(c->pass_done[pass], stream));
         }
     }
-    c->passes_total = progressive ? pass : 0;
-    SRT_HIP(c, hipEventRecord(c->ev_end, stream));
-    c->stats_pending = true;
+    if (&d == &c->dev[0]) c->passes_total = progressive ? pass : 0;
+    SRT_HIP(c, hipEventRecord(d.ev_end, stream));
+    d.stats_pending = true;
     return SRT_OK;
 }
 
-int ensure_out(srt_ctx* c, size_t pixels)
+// The devices of a context as the backend of render_multi(): every step only queues work on the devices' streams;
+// when dev[0]'s stream has drained, the frame is in c->d_frame.
+struct HipDevices {
+    srt_ctx* c;
+    bool counted;
+
+    int prepare(const MultiPlan& plan)
+    {
+        DeviceState& root = c->dev[0];
+        SRT_HIP(c, hipSetDevice(root.device));
+        int rc = ensure_pixels(c, &c->d_gathered, &c->gathered_capacity, (size_t)plan.stride * (size_t)plan.n);
+        if (rc == SRT_OK) rc = ensure_pixels(c, &c->d_frame, &c->frame_capacity, (size_t)plan.frame_pixels);
+        for (int k = 1; k < plan.n && rc == SRT_OK; k++) {
+            DeviceState& d = c->dev[k];
+            SRT_HIP(c, hipSetDevice(d.device));
+            rc = ensure_pixels(c, &d.d_out, &d.out_capacity, (size_t)plan.pixels[k]);
+        }
+        return rc;
+    }
+    // device 0 traces straight into its slot of the gathered array
+    int trace_tiles(int k, const MultiPlan& plan)
+    {
+        DeviceState& d = c->dev[k];
+        uint32_t* out = k == 0 ? c->d_gathered : d.d_out;
+        return launch(c, d, &plan.part[k], out, (size_t)plan.pixels[k], d.stream, counted);
+    }
+    int gather(const MultiPlan& plan)
+    {
+        DeviceState& root = c->dev[0];
+        if (c->gather == SRT_GATHER_RCCL) {
+            // every peer has its own xGMI link to the first device: (n - 1) receives there, one send on each peer
+            SRT_NCCL(c, g_rccl.GroupStart());
+            for (int k = 1; k < plan.n; k++) {
+                if (plan.pixels[k] == 0) continue;
+                SRT_HIP(c, hipSetDevice(root.device));
+                SRT_NCCL(c, g_rccl.Recv(c->d_gathered + (size_t)k * (size_t)plan.stride, (size_t)plan.pixels[k], ncclUint32, k, c->comms[0], root.stream));
+                SRT_HIP(c, hipSetDevice(c->dev[k].device));
+                SRT_NCCL(c, g_rccl.Send(c->dev[k].d_out, (size_t)plan.pixels[k], ncclUint32, 0, c->comms[k], c->dev[k].stream));
+            }
+            SRT_NCCL(c, g_rccl.GroupEnd());
+            return SRT_OK;
+        }
+        for (int k = 1; k < plan.n; k++) {
+            if (plan.pixels[k] == 0) continue;
+            DeviceState& d = c->dev[k];
+            SRT_HIP(c, hipSetDevice(d.device));
+            uint32_t* dst = c->d_gathered + (size_t)k * (size_t)plan.stride;
+            const size_t bytes = (size_t)plan.pixels[k] * sizeof(uint32_t);
+            if (d.device == root.device) SRT_HIP(c, hipMemcpyAsync(dst, d.d_out, bytes, hipMemcpyDeviceToDevice, d.stream));
+            else SRT_HIP(c, hipMemcpyPeerAsync(dst, root.device, d.d_out, d.device, bytes, d.stream));
+            SRT_HIP(c, hipEventRecord(d.ev_tiles, d.stream));
+            SRT_HIP(c, hipSetDevice(root.device));
+            SRT_HIP(c, hipStreamWaitEvent(root.stream, d.ev_tiles, 0));
+        }
+        return SRT_OK;
+    }
+    int assemble(const MultiPlan& plan)
+    {
+        DeviceState& root = c->dev[0];
+        SRT_HIP(c, hipSetDevice(root.device));
+        hipError_t e = launch_assemble(plan.assemble, c->d_gathered, (size_t)plan.stride, c->d_frame, root.stream);
+        if (e != hipSuccess) return hip_fail(c, e, "assemble kernel launch");
+        return SRT_OK;
+    }
+};
+
+// Queues one frame on all devices of the context; the frame ends up in c->d_frame on dev[0]'s stream.
+int launch_multi(srt_ctx* c, const srt_render_params* p, bool counted, MultiPlan& plan)
 {
-    if (pixels <= c->out_capacity) return SRT_OK;
-    if (c->d_out) hipFree(c->d_out);
-    c->d_out = nullptr; c->out_capacity = 0;
-    SRT_HIP(c, hipMalloc((void**)&c->d_out, pixels * sizeof(uint32_t)));
-    c->out_capacity = pixels;
-    return SRT_OK;
+    int rc = plan_multi(p, (int)c->dev.size(), plan, c->error);
+    if (rc != SRT_OK) return rc;
+    HipDevices backend{c, counted};
+    return render_multi(backend, plan);
 }
 
 int render_blocking(srt_ctx* c, const srt_render_params* p, uint32_t* rgba_out, bool counted, int mix_buffers = 0)
@@ -258,16 +456,56 @@ int render_blocking(srt_ctx* c, const srt_render_params* p, uint32_t* rgba_out, 
     if (c->async_pending) return fail(c, SRT_E_STATE, "an asynchronous render is in flight");
     int64_t n = output_pixels(p);
     if (n < 0) { RenderArgs ra; return make_render_args(p, c->cam, ra, c->error); }
-    SRT_HIP(c, hipSetDevice(c->device));
-    int rc = ensure_out(c, (size_t)n);
+    DeviceState& d = c->dev[0];
+    SRT_HIP(c, hipSetDevice(d.device));
+    int rc = collect_stats(c);  // a blocking render reports its own counters only
     if (rc != SRT_OK) return rc;
-    rc = collect_stats(c);  // a blocking render reports its own counters only
-    if (rc != SRT_OK) return rc;
-    rc = launch(c, p, c->d_out, c->out_capacity, c->stream, counted, 1, mix_buffers);
-    if (rc != SRT_OK) return rc;
-    SRT_HIP(c, hipMemcpyAsync(rgba_out, c->d_out, (size_t)n * sizeof(uint32_t), hipMemcpyDeviceToHost, c->stream));
-    SRT_HIP(c, hipStreamSynchronize(c->stream));
+    const uint32_t* src;
+    if (c->dev.size() > 1 && mix_buffers == 0) {
+        MultiPlan plan;
+        if ((rc = launch_multi(c, p, counted, plan)) != SRT_OK) return rc;
+        src = c->d_frame;
+    } else {
+        if ((rc = ensure_pixels(c, &d.d_out, &d.out_capacity, (size_t)n)) != SRT_OK) return rc;
+        if ((rc = launch(c, d, p, d.d_out, d.out_capacity, d.stream, counted, 1, mix_buffers)) != SRT_OK) return rc;
+        src = d.d_out;
+    }
+    SRT_HIP(c, hipSetDevice(d.device));
+    SRT_HIP(c, hipMemcpyAsync(rgba_out, src, (size_t)n * sizeof(uint32_t), hipMemcpyDeviceToHost, d.stream));
+    SRT_HIP(c, hipStreamSynchronize(d.stream));
     return collect_stats(c);
+}
+
+int create_device(DeviceState& d, int ordinal)
+{
+    d.device = ordinal;
+    bool ok = hipSetDevice(ordinal) == hipSuccess && hipStreamCreateWithFlags(&d.stream, hipStreamNonBlocking) == hipSuccess &&
+              hipEventCreate(&d.ev_begin) == hipSuccess && hipEventCreate(&d.ev_end) == hipSuccess &&
+              hipEventCreateWithFlags(&d.ev_tiles, hipEventDisableTiming) == hipSuccess &&
+              hipMalloc((void**)&d.d_stats, 32 * sizeof(unsigned long long)) == hipSuccess &&
+              hipMalloc((void**)&d.d_counter, sizeof(uint32_t)) == hipSuccess &&
+#ifdef SRT_TIMELINE
+              hipMalloc((void**)&d.d_timeline, trace_timeline_bytes()) == hipSuccess &&
+#endif
+              hipMemset(d.d_stats, 0, 32 * sizeof(unsigned long long)) == hipSuccess && hipDeviceSynchronize() == hipSuccess;
+    return ok ? SRT_OK : SRT_E_HIP;
+}
+
+void destroy_device(DeviceState& d)
+{
+    hipSetDevice(d.device);
+    if (d.stream) hipStreamSynchronize(d.stream);
+    free_scene_buffers(d);
+    if (d.d_out) hipFree(d.d_out);
+    if (d.d_stats) hipFree(d.d_stats);
+    if (d.d_counter) hipFree(d.d_counter);
+    if (d.d_timeline) hipFree(d.d_timeline);
+    if (d.d_samples) hipFree(d.d_samples);
+    if (d.d_running) hipFree(d.d_running);
+    if (d.ev_begin) hipEventDestroy(d.ev_begin);
+    if (d.ev_end) hipEventDestroy(d.ev_end);
+    if (d.ev_tiles) hipEventDestroy(d.ev_tiles);
+    if (d.stream) hipStreamDestroy(d.stream);
 }
 
 }  // namespace
@@ -282,34 +520,80 @@ int srt_create(const srt_config* cfg, srt_ctx** out)
 {
     if (!out) return fail(nullptr, SRT_E_INVALID, "out is NULL");
     *out = nullptr;
-    int device = cfg ? cfg->device : 0;
     int count = 0;
     hipError_t e = hipGetDeviceCount(&count);
     if (e != hipSuccess || count <= 0) return fail(nullptr, SRT_E_NO_DEVICE, "no HIP device is visible; this library has no CPU path");
-    if (device < 0 || device >= count) return fail(nullptr, SRT_E_INVALID, "device ordinal out of range");
-    hipDeviceProp_t prop;
-    e = hipGetDeviceProperties(&prop, device);
-    if (e != hipSuccess) return hip_fail(nullptr, e, "hipGetDeviceProperties");
-    if (std::strncmp(prop.gcnArchName, "gfx950", 6) != 0)
-        return fail(nullptr, SRT_E_NO_DEVICE, std::string("kernels are built for gfx950 only, device is ") + prop.gcnArchName);
+    // the device list
+    std::vector<int> ordinals;
+    int gather = SRT_GATHER_RCCL;
+    const int n_cfg = cfg ? cfg->n_devices : 0;
+    if (n_cfg == 0) ordinals.push_back(cfg ? cfg->device : 0);
+    else if (n_cfg == SRT_ALL_DEVICES) {
+        if (count > SRT_MAX_DEVICES) count = SRT_MAX_DEVICES;
+        for (int i = 0; i < count; i++) ordinals.push_back(i);
+    } else if (n_cfg >= 1 && n_cfg <= SRT_MAX_DEVICES) ordinals.assign(cfg->devices, cfg->devices + n_cfg);
+    else return fail(nullptr, SRT_E_INVALID, "n_devices must be 0, SRT_ALL_DEVICES or 1..SRT_MAX_DEVICES");
+    if (n_cfg != 0) {
+        gather = cfg->gather;
+        if (gather != SRT_GATHER_RCCL && gather != SRT_GATHER_PEER_COPY) return fail(nullptr, SRT_E_INVALID, "unknown gather kind");
+        if (const char* g = std::getenv("SRT_GATHER")) {   // experiments: force one transport
+            if (!std::strcmp(g, "peer")) gather = SRT_GATHER_PEER_COPY;
+            else if (!std::strcmp(g, "rccl")) gather = SRT_GATHER_RCCL;
+        }
+    }
+    bool distinct = true;
+    for (size_t i = 0; i < ordinals.size(); i++) {
+        if (ordinals[i] < 0 || ordinals[i] >= count) return fail(nullptr, SRT_E_INVALID, "device ordinal out of range");
+        for (size_t j = 0; j < i; j++) distinct = distinct && ordinals[i] != ordinals[j];
+        hipDeviceProp_t prop;
+        e = hipGetDeviceProperties(&prop, ordinals[i]);
+        if (e != hipSuccess) return hip_fail(nullptr, e, "hipGetDeviceProperties");
+        if (std::strncmp(prop.gcnArchName, "gfx950", 6) != 0)
+            return fail(nullptr, SRT_E_NO_DEVICE, std::string("kernels are built for gfx950 only, device is ") + prop.gcnArchName);
+    }
     srt_ctx* c = new srt_ctx();
-    c->device = device;
-    bool ok = hipSetDevice(device) == hipSuccess && hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) == hipSuccess &&
-              hipEventCreate(&c->ev_begin) == hipSuccess && hipEventCreate(&c->ev_end) == hipSuccess &&
-              hipMalloc((void**)&c->d_stats, 32 * sizeof(unsigned long long)) == hipSuccess &&
-              hipMalloc((void**)&c->d_counter, sizeof(uint32_t)) == hipSuccess &&
-#ifdef SRT_TIMELINE
-              hipMalloc((void**)&c->d_timeline, trace_timeline_bytes()) == hipSuccess &&
-#endif
-              hipMemset(c->d_stats, 0, 32 * sizeof(unsigned long long)) == hipSuccess && hipDeviceSynchronize() == hipSuccess;
-    if (!ok) {
-        srt_destroy(c);
-        return fail(nullptr, SRT_E_HIP, "could not create stream / events / counters on the device");
+    c->dev.resize(ordinals.size());
+    for (size_t i = 0; i < ordinals.size(); i++) {
+        if (create_device(c->dev[i], ordinals[i]) != SRT_OK) {
+            srt_destroy(c);
+            return fail(nullptr, SRT_E_HIP, "could not create stream / events / counters on the device");
+        }
+    }
+    // RCCL refuses a communicator with one GPU in two ranks, and one device has nothing to gather
+    c->gather = (ordinals.size() > 1 && distinct) ? gather : SRT_GATHER_PEER_COPY;
+    if (ordinals.size() > 1) {
+        // direct xGMI access between the first device and the others, where the platform offers it
+        for (size_t i = 1; i < ordinals.size(); i++) {
+            if (ordinals[i] == ordinals[0]) continue;
+            int can = 0;
+            if (hipDeviceCanAccessPeer(&can, ordinals[i], ordinals[0]) == hipSuccess && can) { hipSetDevice(ordinals[i]); (void)hipDeviceEnablePeerAccess(ordinals[0], 0); }
+            if (hipDeviceCanAccessPeer(&can, ordinals[0], ordinals[i]) == hipSuccess && can) { hipSetDevice(ordinals[0]); (void)hipDeviceEnablePeerAccess(ordinals[i], 0); }
+        }
+        (void)hipGetLastError();   // "peer access already enabled" is not an error here
+    }
+    if (c->gather == SRT_GATHER_RCCL) {
+        std::string err;
+        if (!g_rccl.load(err)) { srt_destroy(c); return fail(nullptr, SRT_E_HIP, err + " (gather = SRT_GATHER_PEER_COPY needs no RCCL)"); }
+        ncclResult_t r = g_rccl.CommInitAll(c->comms, (int)ordinals.size(), ordinals.data());
+        if (r != ncclSuccess) {
+            std::string msg = std::string("ncclCommInitAll: ") + g_rccl.GetErrorString(r);
+            for (ncclComm_t& k : c->comms) k = nullptr;
+            srt_destroy(c);
+            return fail(nullptr, SRT_E_HIP, msg);
+        }
+        int ranks = 0;
+        r = g_rccl.CommCount(c->comms[0], &ranks);
+        c->rccl_ranks = ranks;
+        if (r != ncclSuccess || ranks != (int)ordinals.size()) {
+            srt_destroy(c);
+            return fail(nullptr, SRT_E_HIP, "the RCCL communicator does not have one rank per device of the context");
+        }
     }
     if (const char* mb = std::getenv("SRT_SAMPLE_BUFFER_MB")) {
         long v = std::atol(mb);
         if (v > 0) c->sample_budget = (uint64_t)v << 20;
     }
+    hipSetDevice(ordinals[0]);
     *out = c;
     return SRT_OK;
 }
@@ -317,22 +601,32 @@ int srt_create(const srt_config* cfg, srt_ctx** out)
 void srt_destroy(srt_ctx* c)
 {
     if (!c) return;
-    hipSetDevice(c->device);
-    if (c->stream) hipStreamSynchronize(c->stream);
-    free_scene_buffers(c);
-    if (c->d_out) hipFree(c->d_out);
-    if (c->d_stats) hipFree(c->d_stats);
-    if (c->d_counter) hipFree(c->d_counter);
-    if (c->d_timeline) hipFree(c->d_timeline);
-    if (c->d_mix) hipFree(c->d_mix);
-    if (c->d_samples) hipFree(c->d_samples);
-    if (c->d_running) hipFree(c->d_running);
-    if (c->h_pinned) hipHostFree(c->h_pinned);
-    for (hipEvent_t e : c->pass_done) if (e) hipEventDestroy(e);
-    if (c->ev_begin) hipEventDestroy(c->ev_begin);
-    if (c->ev_end) hipEventDestroy(c->ev_end);
-    if (c->stream) hipStreamDestroy(c->stream);
+    for (DeviceState& d : c->dev) if (d.stream) { hipSetDevice(d.device); hipStreamSynchronize(d.stream); }
+    for (ncclComm_t k : c->comms) if (k) g_rccl.CommDestroy(k);
+    if (!c->dev.empty()) {
+        hipSetDevice(c->dev[0].device);
+        if (c->d_gathered) hipFree(c->d_gathered);
+        if (c->d_frame) hipFree(c->d_frame);
+        if (c->d_mix) hipFree(c->d_mix);
+        if (c->d_post[0]) hipFree(c->d_post[0]);
+        if (c->d_post[1]) hipFree(c->d_post[1]);
+        if (c->d_post_progress) hipFree(c->d_post_progress);
+        if (c->h_pinned) hipHostFree(c->h_pinned);
+        for (hipEvent_t e : c->pass_done) if (e) hipEventDestroy(e);
+    }
+    for (DeviceState& d : c->dev) destroy_device(d);
     delete c;
+}
+
+int srt_get_device_info(const srt_ctx* c, srt_device_info* out)
+{
+    if (!c || !out) return SRT_E_INVALID;
+    std::memset(out, 0, sizeof(*out));
+    out->n_devices = (int32_t)c->dev.size();
+    for (size_t i = 0; i < c->dev.size(); i++) out->devices[i] = c->dev[i].device;
+    out->gather = c->gather;
+    out->rccl_ranks = c->rccl_ranks;
+    return SRT_OK;
 }
 
 int srt_set_camera(srt_ctx* c, const float position[3], const float lower_left[3], const float horizontal[3], const float vertical[3])
@@ -386,15 +680,18 @@ int srt_commit_scene(srt_ctx* c, int world_kind)
     c->committed = false;
     int rc = flatten_scene(c->host, world_kind, c->flat, c->error);
     if (rc != SRT_OK) return rc;
-    SRT_HIP(c, hipSetDevice(c->device));
-    SRT_HIP(c, hipStreamSynchronize(c->stream));
-    free_scene_buffers(c);
-    if ((rc = upload(c, c->flat.nodes, &c->d_nodes)) != SRT_OK) return rc;
-    if ((rc = upload(c, c->flat.prims, &c->d_prims)) != SRT_OK) return rc;
-    if ((rc = upload(c, c->flat.normals, &c->d_normals)) != SRT_OK) return rc;
-    if ((rc = upload(c, c->flat.materials, &c->d_materials)) != SRT_OK) return rc;
-    if ((rc = upload(c, c->flat.lights, &c->d_lights)) != SRT_OK) return rc;
-    if ((rc = upload(c, c->flat.tiny, &c->d_tiny)) != SRT_OK) return rc;
+    // one replica per device: no scene traffic between devices while tracing
+    for (DeviceState& d : c->dev) {
+        SRT_HIP(c, hipSetDevice(d.device));
+        SRT_HIP(c, hipStreamSynchronize(d.stream));
+        free_scene_buffers(d);
+        if ((rc = upload(c, c->flat.nodes, &d.d_nodes)) != SRT_OK) return rc;
+        if ((rc = upload(c, c->flat.prims, &d.d_prims)) != SRT_OK) return rc;
+        if ((rc = upload(c, c->flat.normals, &d.d_normals)) != SRT_OK) return rc;
+        if ((rc = upload(c, c->flat.materials, &d.d_materials)) != SRT_OK) return rc;
+        if ((rc = upload(c, c->flat.lights, &d.d_lights)) != SRT_OK) return rc;
+        if ((rc = upload(c, c->flat.tiny, &d.d_tiny)) != SRT_OK) return rc;
+    }
     c->world_kind = world_kind;
     c->committed = true;
     c->stats.build_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
@@ -414,7 +711,7 @@ int srt_render_counted(srt_ctx* c, const srt_render_params* p, uint32_t* rgba_ou
 int srt_render_device(srt_ctx* c, const srt_render_params* p, void* d_rgba_out, size_t capacity_pixels, void* hip_stream)
 {
     if (!c) return SRT_E_INVALID;
-    return launch(c, p, (uint32_t*)d_rgba_out, capacity_pixels, (hipStream_t)hip_stream, false);
+    return launch(c, c->dev[0], p, (uint32_t*)d_rgba_out, capacity_pixels, (hipStream_t)hip_stream, false);
 }
 
 static int start_async(srt_ctx* c, const srt_render_params* p, uint32_t* rgba_out, int passes)
@@ -424,20 +721,29 @@ static int start_async(srt_ctx* c, const srt_render_params* p, uint32_t* rgba_ou
     if (c->async_pending) return fail(c, SRT_E_STATE, "an asynchronous render is already in flight");
     int64_t n = output_pixels(p);
     if (n < 0) { RenderArgs ra; return make_render_args(p, c->cam, ra, c->error); }
-    SRT_HIP(c, hipSetDevice(c->device));
-    int rc = ensure_out(c, (size_t)n);
-    if (rc != SRT_OK) return rc;
+    DeviceState& d = c->dev[0];
+    SRT_HIP(c, hipSetDevice(d.device));
     if ((size_t)n > c->pinned_capacity) {
         if (c->h_pinned) hipHostFree(c->h_pinned);
         c->h_pinned = nullptr; c->pinned_capacity = 0;
         SRT_HIP(c, hipHostMalloc((void**)&c->h_pinned, (size_t)n * sizeof(uint32_t), hipHostMallocDefault));
         c->pinned_capacity = (size_t)n;
     }
-    rc = launch(c, p, c->d_out, c->out_capacity, c->stream, false, passes);
-    if (rc != SRT_OK) return rc;
+    int rc;
+    const uint32_t* src;
+    if (c->dev.size() > 1 && passes == 1) {
+        MultiPlan plan;
+        if ((rc = launch_multi(c, p, false, plan)) != SRT_OK) return rc;
+        src = c->d_frame;
+        SRT_HIP(c, hipSetDevice(d.device));
+    } else {
+        if ((rc = ensure_pixels(c, &d.d_out, &d.out_capacity, (size_t)n)) != SRT_OK) return rc;
+        if ((rc = launch(c, d, p, d.d_out, d.out_capacity, d.stream, false, passes)) != SRT_OK) return rc;
+        src = d.d_out;
+    }
     // ev_end marks the end of the kernels; the copy to pinned memory follows it on the same stream (a progressive
     // render has already queued that copy after its last pass)
-    if (c->passes_total == 0) SRT_HIP(c, hipMemcpyAsync(c->h_pinned, c->d_out, (size_t)n * sizeof(uint32_t), hipMemcpyDeviceToHost, c->stream));
+    if (c->passes_total == 0) SRT_HIP(c, hipMemcpyAsync(c->h_pinned, src, (size_t)n * sizeof(uint32_t), hipMemcpyDeviceToHost, d.stream));
     c->async_dst = rgba_out;
     c->async_pixels = (size_t)n;
     c->async_pending = true;
@@ -480,12 +786,13 @@ static int finish_async(srt_ctx* c)
     return collect_stats(c);
 }
 
+// dev[0]'s stream has everything behind it: the other devices' tiles arrive there before the frame is assembled
 int srt_poll(srt_ctx* c, int* done)
 {
     if (!c) return SRT_E_INVALID;
     if (!done) return fail(c, SRT_E_INVALID, "done is NULL");
     if (!c->async_pending) { *done = 1; return SRT_OK; }
-    hipError_t e = hipStreamQuery(c->stream);
+    hipError_t e = hipStreamQuery(c->dev[0].stream);
     if (e == hipErrorNotReady) { *done = 0; return SRT_OK; }
     if (e != hipSuccess) return hip_fail(c, e, "hipStreamQuery");
     *done = 1;
@@ -496,7 +803,7 @@ int srt_wait(srt_ctx* c)
 {
     if (!c) return SRT_E_INVALID;
     if (!c->async_pending) return SRT_OK;
-    SRT_HIP(c, hipStreamSynchronize(c->stream));
+    SRT_HIP(c, hipStreamSynchronize(c->dev[0].stream));
     return finish_async(c);
 }
 
@@ -510,22 +817,32 @@ int srt_get_stats(srt_ctx* c, srt_stats* out)
     return SRT_OK;
 }
 
+int srt_get_device_stats(srt_ctx* c, int32_t index, srt_stats* out)
+{
+    if (!c) return SRT_E_INVALID;
+    if (!out) return fail(c, SRT_E_INVALID, "out is NULL");
+    if (index < 0 || (size_t)index >= c->dev.size()) return fail(c, SRT_E_INVALID, "device index out of range");
+    *out = c->dev[(size_t)index].part;
+    out->build_ms = c->stats.build_ms; out->bvh_nodes = c->stats.bvh_nodes; out->bvh_depth = c->stats.bvh_depth; out->n_prims = c->stats.n_prims;
+    return SRT_OK;
+}
+
 int64_t srt_local_pixels(const srt_render_params* p) { return output_pixels(p); }
 
 int srt_assemble_tiles(srt_ctx* c, const srt_render_params* p, const void* d_gathered, size_t stride_pixels, void* d_frame, void* hip_stream)
 {
     if (!c) return SRT_E_INVALID;
+    if (!p) return fail(c, SRT_E_INVALID, "params is NULL");
     if (!d_gathered || !d_frame) return fail(c, SRT_E_INVALID, "device pointer is NULL");
     RenderArgs ra;
     Camera none{};
     srt_render_params q = *p;
     q.rank = 0;
+    q.layout = SRT_LAYOUT_TILES;
     int rc = make_render_args(&q, none, ra, c->error);
     if (rc != SRT_OK) return rc;
-    srt_render_params worst = q;
-    worst.layout = SRT_LAYOUT_TILES;
-    if ((int64_t)stride_pixels < output_pixels(&worst)) return fail(c, SRT_E_INVALID, "stride_pixels smaller than rank 0's tile buffer");
-    SRT_HIP(c, hipSetDevice(c->device));
+    if ((int64_t)stride_pixels < output_pixels(&q)) return fail(c, SRT_E_INVALID, "stride_pixels smaller than rank 0's tile buffer");
+    SRT_HIP(c, hipSetDevice(c->dev[0].device));
     hipStream_t s = (hipStream_t)hip_stream;
     hipError_t e = launch_assemble(ra, (const uint32_t*)d_gathered, stride_pixels, (uint32_t*)d_frame, s);
     if (e != hipSuccess) return hip_fail(c, e, "assemble kernel launch");
@@ -544,26 +861,30 @@ int post_filter(srt_ctx* c, int filter, uint32_t* array, int32_t width, int32_t 
     if (passes < 1) return fail(c, SRT_E_INVALID, "passes must be at least 1");
     if ((int64_t)width * (int64_t)height > ((int64_t)1 << 31) - 1) return fail(c, SRT_E_LIMIT, "more than 2^31 pixels");
     if (c->async_pending) return fail(c, SRT_E_STATE, "an asynchronous render is in flight");
-    SRT_HIP(c, hipSetDevice(c->device));
-    const size_t bytes = (size_t)width * (size_t)height * sizeof(uint32_t);
-    uint32_t* d[2] = {nullptr, nullptr};
-    uint32_t* d_progress = nullptr;
+    DeviceState& dv = c->dev[0];
+    SRT_HIP(c, hipSetDevice(dv.device));
+    const size_t pixels = (size_t)width * (size_t)height, bytes = pixels * sizeof(uint32_t);
     const size_t progress_bytes = post_progress_bytes();
+    // the two pictures and the progress words stay with the context: filtering one size again allocates nothing
+    if (pixels > c->post_capacity || !c->d_post[0] || !c->d_post[1]) {
+        SRT_HIP(c, hipDeviceSynchronize());
+        for (uint32_t*& b : c->d_post) { if (b) (void)hipFree(b); b = nullptr; }
+        c->post_capacity = 0;
+        SRT_HIP(c, hipMalloc((void**)&c->d_post[0], bytes));
+        SRT_HIP(c, hipMalloc((void**)&c->d_post[1], bytes));
+        c->post_capacity = pixels;
+    }
+    if (!c->d_post_progress) SRT_HIP(c, hipMalloc((void**)&c->d_post_progress, progress_bytes));
+    uint32_t* const* d = c->d_post;
     uint32_t alarm = 0u;
-    hipError_t e = hipMalloc((void**)&d[0], bytes);
-    if (e == hipSuccess) e = hipMalloc((void**)&d[1], bytes);
-    if (e == hipSuccess) e = hipMalloc((void**)&d_progress, progress_bytes);
-    if (e == hipSuccess) e = hipMemsetAsync(d_progress, 0, progress_bytes, c->stream);
-    if (e == hipSuccess) e = hipMemcpyAsync(d[0], array, bytes, hipMemcpyHostToDevice, c->stream);
+    hipError_t e = hipMemsetAsync(c->d_post_progress, 0, progress_bytes, dv.stream);
+    if (e == hipSuccess) e = hipMemcpyAsync(d[0], array, bytes, hipMemcpyHostToDevice, dv.stream);
     int from = 0;
     for (int32_t i = 0; i < passes && e == hipSuccess; i++, from ^= 1)
-        e = launch_post_filter(filter, d[from], d[from ^ 1], width, height, weight, param, d_progress, c->stream);
-    if (e == hipSuccess) e = hipMemcpyAsync(array, d[from], bytes, hipMemcpyDeviceToHost, c->stream);
-    if (e == hipSuccess) e = hipMemcpyAsync(&alarm, reinterpret_cast<char*>(d_progress) + progress_bytes - sizeof(uint32_t), sizeof(uint32_t), hipMemcpyDeviceToHost, c->stream);
-    if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
-    if (d[0]) (void)hipFree(d[0]);
-    if (d[1]) (void)hipFree(d[1]);
-    if (d_progress) (void)hipFree(d_progress);
+        e = launch_post_filter(filter, d[from], d[from ^ 1], width, height, weight, param, c->d_post_progress, dv.stream);
+    if (e == hipSuccess) e = hipMemcpyAsync(array, d[from], bytes, hipMemcpyDeviceToHost, dv.stream);
+    if (e == hipSuccess) e = hipMemcpyAsync(&alarm, reinterpret_cast<char*>(c->d_post_progress) + progress_bytes - sizeof(uint32_t), sizeof(uint32_t), hipMemcpyDeviceToHost, dv.stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(dv.stream);
     if (e != hipSuccess) return hip_fail(c, e, "post-process filter");
     if (alarm != 0u) return fail(c, SRT_E_HIP, "post-process filter: a band of rows gave up waiting for the band above it; the picture is incomplete");
     return SRT_OK;

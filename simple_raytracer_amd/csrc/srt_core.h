@@ -784,5 +784,18 @@ SRT_HD bool work_to_pixel(const RenderArgs& ra, uint32_t w, int32_t& x, int32_t&
     return x < ra.width && y < ra.height && ty < (uint32_t)ra.tiles_y;
 }
 
+// Where pixel i = x + y * width of the frame sits in the gathered tile buffers of a partitioned render (rank r's buffer
+// starts at r * stride): tile t = tx + ty * tiles_x belongs to rank t % world_size, which holds it as its (t / world_size)-th
+// tile, row-major inside the tile.  The inverse of work_to_pixel's SRT_LAYOUT_TILES output index.
+SRT_HD size_t gathered_index(const RenderArgs& ra, uint32_t i, size_t stride)
+{
+    uint32_t y = i / (uint32_t)ra.width, x = i - y * (uint32_t)ra.width;
+    uint32_t tx = x / (uint32_t)ra.tile_w, ty = y / (uint32_t)ra.tile_h;
+    uint32_t lx = x - tx * (uint32_t)ra.tile_w, ly = y - ty * (uint32_t)ra.tile_h;
+    uint32_t t = tx + ty * (uint32_t)ra.tiles_x;
+    uint32_t r = t % (uint32_t)ra.world_size, j = t / (uint32_t)ra.world_size;
+    return (size_t)r * stride + (size_t)j * (uint32_t)(ra.tile_w * ra.tile_h) + ly * (uint32_t)ra.tile_w + lx;
+}
+
 }  // namespace srt
 #endif  // SRT_CORE_H

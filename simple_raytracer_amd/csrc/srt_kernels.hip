@@ -712,12 +712,7 @@ __global__ void __launch_bounds__(kBlock) assemble_kernel(RenderArgs ra, const u
     uint32_t i = blockIdx.x * (uint32_t)kBlock + threadIdx.x;
     uint32_t total = (uint32_t)ra.width * (uint32_t)ra.height;
     if (i >= total) return;
-    uint32_t y = i / (uint32_t)ra.width, x = i - y * (uint32_t)ra.width;
-    uint32_t tx = x / (uint32_t)ra.tile_w, ty = y / (uint32_t)ra.tile_h;
-    uint32_t lx = x - tx * (uint32_t)ra.tile_w, ly = y - ty * (uint32_t)ra.tile_h;
-    uint32_t t = tx + ty * (uint32_t)ra.tiles_x;
-    uint32_t r = t % (uint32_t)ra.world_size, j = t / (uint32_t)ra.world_size;
-    frame[i] = gathered[(size_t)r * stride + (size_t)j * (uint32_t)(ra.tile_w * ra.tile_h) + ly * (uint32_t)ra.tile_w + lx];
+    frame[i] = gathered[gathered_index(ra, i, stride)];
 }
 
 // Blocks of a persistent kernel that the device keeps resident at once.  More than that is useless: the surplus only
@@ -815,6 +810,7 @@ hipError_t launch_trace(const SceneView& sc, const RenderArgs& ra_in, bool exact
     return hipGetLastError();
 }
 
+size_t trace_timeline_records() { return (size_t)kMaxBlocks * kWaves; }
 size_t trace_timeline_offset() { return (size_t)1100 * kWaves * kTimelinePerWave * sizeof(float4); }
 size_t trace_timeline_bytes() { return (size_t)kMaxBlocks * kWaves * kTimelinePerWave * sizeof(float4); }
 

@@ -16,6 +16,7 @@ namespace srt {
 hipError_t launch_trace(const SceneView& sc, const RenderArgs& ra, bool exact, bool counted, float* d_samples,
                         unsigned long long* d_stats, uint32_t* d_work_counter, float* d_timeline, hipStream_t stream);
 size_t trace_timeline_bytes();
+size_t trace_timeline_records();  // experiments: how many records (4 x uint64 each, one per wavefront of the largest grid) there are
 size_t trace_timeline_offset();   // experiments: where a -DSRT_TIMELINE build leaves its per-wavefront clock records in d_timeline
 // Adds the pass's samples to the per-pixel running sums (3 floats per pixel; untouched when the pass is both the
 // first and the last) and, on the last pass, writes the packed pixels.  preview_scale > 0: earlier passes write a

@@ -69,7 +69,14 @@ __global__ void __launch_bounds__(kBandRows) post_band_kernel(const uint32_t* __
                     unsigned long long polls = 0ull;
                     do {
                         known = __hip_atomic_load(&progress[band - 1], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT);
-                        if (++polls > kPostMaxPolls) { __hip_atomic_store(&progress[kMaxBands], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); break; }
+                        // Giving up is final: the alarm is raised once, this band stops waiting for good, and its own
+                        // progress word reports every column as done, so the bands below leave as well instead of
+                        // each spinning through the poll budget for every column.
+                        if (++polls > kPostMaxPolls || __hip_atomic_load(&progress[kMaxBands], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) {
+                            __hip_atomic_store(&progress[kMaxBands], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                            __hip_atomic_store(&progress[band], 0x7FFFFFFFu, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+                            known = 0x7FFFFFFFu;
+                        }
                     } while (known < need);
                 }
                 w.left_up = above_out[x - 1]; w.up = above_out[x]; w.right_up = above_out[x + 1];

@@ -676,6 +676,8 @@ static int check_params(const srt_render_params* p, int& tw, int& th, int& world
     if (tw <= 0 || th <= 0 || (tw & 7) || (th & 7) || tw > 4096 || th > 4096) return fail(SRT_E_INVALID, "tile size must be a positive multiple of 8");
     world = p->world_size > 1 ? p->world_size : 1;
     if (p->rank < 0 || p->rank >= world) return fail(SRT_E_INVALID, "rank out of range");
+    // a rank of several writes only its own tiles: a row-major frame would keep stale pixels everywhere else
+    if (world > 1 && p->layout == SRT_LAYOUT_FRAME) return fail(SRT_E_INVALID, "a rank of several renders into SRT_LAYOUT_TILES; srt_assemble_tiles makes the frame");
     return SRT_OK;
 }
 

@@ -17,16 +17,34 @@ def _up(a):
 
 
 class Renderer:
-    """Owns one libsrt context (one GPU).  Not thread-safe, like the single UI thread of Game1."""
+    """Owns one libsrt context: one GPU (`device`), or a list of them (`devices`: HIP ordinals, or "all") over which the
+    library splits every frame, as Game1 splits it over its worker threads (Game1.cs:161-167).  Not thread-safe, like
+    the single UI thread of Game1."""
 
-    def __init__(self, device=0, library=None, strict=True):
+    def __init__(self, device=0, library=None, strict=True, devices=None, gather=N.GATHER_RCCL):
         self._lib = N.load(library, strict=strict)
         self._ctx = N._CTX()
-        cfg = N.Config(device=device, reserved=0)
+        cfg = N.Config(device=device)
+        if devices == "all":
+            cfg.n_devices = N.ALL_DEVICES
+        elif devices is not None:
+            devices = [int(d) for d in devices]
+            if not 1 <= len(devices) <= N.MAX_DEVICES:
+                raise ValueError("1..%d devices" % N.MAX_DEVICES)
+            cfg.n_devices = len(devices)
+            for i, d in enumerate(devices):
+                cfg.devices[i] = d
+        cfg.gather = int(gather)
         rc = self._lib.srt_create(C.byref(cfg), C.byref(self._ctx))
         if rc != N.OK:
             raise N.SrtError(rc, self._lib.srt_last_error(None).decode())
-        self.device = device
+        self.device = device if devices is None else (devices[0] if devices != "all" else 0)
+
+    def device_info(self):
+        """-> {"devices": [HIP ordinals], "gather": GATHER_*, "rccl_ranks": ranks of the RCCL communicator or 0}."""
+        info = N.DeviceInfo()
+        self._check(self._lib.srt_get_device_info(self._ctx, C.byref(info)))
+        return {"devices": [info.devices[i] for i in range(info.n_devices)], "gather": info.gather, "rccl_ranks": info.rccl_ranks}
 
     def close(self):
         if getattr(self, "_ctx", None):
@@ -163,12 +181,22 @@ class Renderer:
         self._check(self._lib.srt_assemble_tiles(self._ctx, C.byref(p), C.c_void_p(gathered_ptr), stride_pixels,
                                                  C.c_void_p(frame_ptr), C.c_void_p(stream or 0)))
 
-    def stats(self):
-        st = N.Stats()
-        self._check(self._lib.srt_get_stats(self._ctx, C.byref(st)))
+    @staticmethod
+    def _stats_dict(st):
         out = {k: getattr(st, k) for k, _ in N.Stats._fields_ if k != "reserved"}
         out["section_cycles"] = list(st.section_cycles)
         return out
+
+    def stats(self):
+        st = N.Stats()
+        self._check(self._lib.srt_get_stats(self._ctx, C.byref(st)))
+        return self._stats_dict(st)
+
+    def device_stats(self, index):
+        """One device's share (index = position in the device list) of what stats() last collected."""
+        st = N.Stats()
+        self._check(self._lib.srt_get_device_stats(self._ctx, int(index), C.byref(st)))
+        return self._stats_dict(st)
 
 
 def rgba_to_rgb8(img):

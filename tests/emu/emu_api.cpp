@@ -13,6 +13,7 @@
 #include "../../include/srt.h"
 #include <algorithm>
 
+#include "../../simple_raytracer_amd/csrc/srt_multi.h"
 #include "../../simple_raytracer_amd/csrc/srt_path.h"
 #include "../../simple_raytracer_amd/csrc/srt_post.h"
 #include "../../simple_raytracer_amd/csrc/srt_scene.h"
@@ -27,6 +28,7 @@ struct srt_ctx {
     Camera cam{};
     bool has_camera = false;
     srt_stats stats{};
+    int n_devices = 1;          // virtual devices: the frame is partitioned as libsrt.so partitions it over GPUs
     std::string error;
 };
 
@@ -123,7 +125,24 @@ extern "C" {
 
 int srt_version(void) { return SRT_VERSION; }
 const char* srt_last_error(const srt_ctx* c) { return c ? c->error.c_str() : ""; }
-int srt_create(const srt_config*, srt_ctx** out) { *out = new srt_ctx(); return SRT_OK; }
+int srt_create(const srt_config* cfg, srt_ctx** out)
+{
+    *out = nullptr;
+    int n = cfg ? cfg->n_devices : 0;
+    if (n == 0 || n == SRT_ALL_DEVICES) n = 1;
+    if (n < 1 || n > SRT_MAX_DEVICES) return SRT_E_INVALID;
+    *out = new srt_ctx();
+    (*out)->n_devices = n;
+    return SRT_OK;
+}
+int srt_get_device_info(const srt_ctx* c, srt_device_info* out)
+{
+    if (!c || !out) return SRT_E_INVALID;
+    std::memset(out, 0, sizeof(*out));
+    out->n_devices = c->n_devices;
+    out->gather = SRT_GATHER_PEER_COPY;
+    return SRT_OK;
+}
 void srt_destroy(srt_ctx* c) { delete c; }
 
 int srt_set_camera(srt_ctx* c, const float p[3], const float l[3], const float h[3], const float v[3])
@@ -221,7 +240,58 @@ static int render_passes(srt_ctx* c, const srt_render_params* p, uint32_t* out, 
     c->stats.box_tests = s[3]; c->stats.sphere_tests = s[4]; c->stats.tri_tests = s[5]; c->stats.rect_tests = s[6];
     return SRT_OK;
 }
-int srt_render(srt_ctx* c, const srt_render_params* p, uint32_t* out) { return render_passes(c, p, out, 0); }
+
+// The virtual devices of a context as the backend of render_multi(): the orchestration libsrt.so runs over its GPUs
+// (srt_multi.h), with host memory in place of device memory and copies in place of the gather.
+struct EmuDevices {
+    srt_ctx* c;
+    uint32_t* frame;
+    std::vector<uint32_t> gathered;
+    std::vector<std::vector<uint32_t>> tiles;
+    srt_stats total{};
+    int prepare(const MultiPlan& plan)
+    {
+        gathered.assign((size_t)plan.stride * (size_t)plan.n, 0xDEADBEEFu);
+        tiles.resize((size_t)plan.n);
+        for (int k = 1; k < plan.n; k++) tiles[(size_t)k].assign((size_t)plan.pixels[k], 0xDEADBEEFu);
+        return SRT_OK;
+    }
+    int trace_tiles(int k, const MultiPlan& plan)
+    {
+        if (plan.pixels[k] == 0) return SRT_OK;
+        uint32_t* out = k == 0 ? gathered.data() : tiles[(size_t)k].data();
+        int rc = render_passes(c, &plan.part[k], out, 0);
+        total.rays_path += c->stats.rays_path; total.rays_shadow += c->stats.rays_shadow; total.hit_nodes += c->stats.hit_nodes;
+        total.box_tests += c->stats.box_tests; total.sphere_tests += c->stats.sphere_tests; total.tri_tests += c->stats.tri_tests;
+        total.rect_tests += c->stats.rect_tests;
+        return rc;
+    }
+    int gather(const MultiPlan& plan)
+    {
+        for (int k = 1; k < plan.n; k++)
+            std::memcpy(gathered.data() + (size_t)k * (size_t)plan.stride, tiles[(size_t)k].data(), (size_t)plan.pixels[k] * sizeof(uint32_t));
+        return SRT_OK;
+    }
+    int assemble(const MultiPlan& plan)
+    {
+        for (uint32_t i = 0; i < (uint32_t)plan.frame_pixels; i++) frame[i] = gathered[gathered_index(plan.assemble, i, (size_t)plan.stride)];   // assemble_kernel
+        return SRT_OK;
+    }
+};
+
+int srt_render(srt_ctx* c, const srt_render_params* p, uint32_t* out)
+{
+    if (c->n_devices == 1) return render_passes(c, p, out, 0);
+    MultiPlan plan;
+    int rc = plan_multi(p, c->n_devices, plan, c->error);
+    if (rc != SRT_OK) return rc;
+    EmuDevices backend{c, out, {}, {}, {}};
+    rc = render_multi(backend, plan);
+    const srt_stats& t = backend.total;
+    c->stats.rays_path = t.rays_path; c->stats.rays_shadow = t.rays_shadow; c->stats.hit_nodes = t.hit_nodes;
+    c->stats.box_tests = t.box_tests; c->stats.sphere_tests = t.sphere_tests; c->stats.tri_tests = t.tri_tests; c->stats.rect_tests = t.rect_tests;
+    return rc;
+}
 int srt_render_mix_buffers(srt_ctx* c, const srt_render_params* p, int32_t n_buffers, uint32_t* out)
 {
     if (n_buffers < 1 || p->layout != 0 || p->world_size > 1) return SRT_E_INVALID;

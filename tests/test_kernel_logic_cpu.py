@@ -129,3 +129,45 @@ def test_thread_built_tree_of_a_large_mesh_matches_linear_scan(emu, oracle):
     lsb, npx, colours, nodes = mesh_cases.large_mesh_window(emu, oracle)
     assert (lsb, npx) == (0, 0)
     assert colours > 20 and nodes > 10000
+
+
+@pytest.mark.parametrize("n_devices", [1, 2, 3, 8])
+@pytest.mark.parametrize("size,tile", [((200, 120), 0), ((70, 45), 16), ((33, 17), 32)])
+def test_frame_split_over_virtual_devices_is_the_single_device_frame(emu, emu_lib, n_devices, size, tile):
+    """The host orchestration of a context with several devices (plan, per-device tiles, gather, scatter into the
+    frame: srt_multi.h, the code libsrt.so runs over its GPUs) on the harness's virtual devices: the frame and the ray
+    counts do not depend on the number of devices, including devices that own no tile (33 x 17 is one 32 x 32 tile...
+    two with the edge; 8 devices leave six without work)."""
+    import helpers
+    width, height = size
+    world, lights, cam = helpers.default_spec().host(width, height)
+    emu.set_scene(world, lights, cam)
+    ref = emu.render(width, height, samples=3, max_depth=4, seed=7)
+    ref_st = emu.stats()
+    multi = srt.Renderer(library=emu_lib, strict=False, devices=[0] * n_devices)
+    assert len(multi.device_info()["devices"]) == n_devices
+    multi.set_scene(world, lights, cam)
+    img = multi.render(width, height, samples=3, max_depth=4, seed=7, tile_w=tile, tile_h=tile)
+    st = multi.stats()
+    multi.close()
+    assert (img == ref).all()
+    for k in ("rays_path", "rays_shadow", "hit_nodes", "box_tests", "sphere_tests"):
+        assert st[k] == ref_st[k], k
+
+
+def test_a_context_with_several_devices_partitions_the_frame_itself(emu_lib):
+    import helpers
+    multi = srt.Renderer(library=emu_lib, strict=False, devices=[0, 0])
+    world, lights, cam = helpers.default_spec().host(64, 36)
+    multi.set_scene(world, lights, cam)
+    with pytest.raises(srt.SrtError) as e:
+        multi.render(64, 36, samples=1, layout=srt.LAYOUT_TILES, tile_w=32, tile_h=32, rank=1, world_size=2)
+    assert e.value.code == srt._native.E_INVALID
+    multi.close()
+
+
+def test_a_rank_of_several_cannot_render_a_row_major_frame(emu):
+    """Only the rank's own tiles would be written: the rest of the frame would be whatever the buffer held."""
+    import ctypes as C
+    p = emu.params(64, 36, layout=srt.LAYOUT_FRAME, rank=0, world_size=2)
+    assert emu._lib.srt_local_pixels(C.byref(p)) == srt._native.E_INVALID

@@ -201,6 +201,19 @@ int  srt_render(srt_ctx* ctx, const srt_render_params* p, uint32_t* rgba_out);
  * for the gather.  capacity_pixels is the size of d_rgba_out in pixels.  The counters of such launches
  * accumulate until srt_get_stats is called. */
 int  srt_render_device(srt_ctx* ctx, const srt_render_params* p, void* d_rgba_out, size_t capacity_pixels, void* hip_stream);
+/* No counterpart in the reference.  srt_render_device for callers that cannot allocate device memory while they
+ * call it (code under HIP graph capture, tight serving loops, harnesses that forbid hipMalloc): the sample buffer,
+ * the running sums and the work counter live in a static array of SRT_STATIC_SCRATCH_BYTES that every GPU the
+ * library runs on holds until the process ends, and the call makes no hipMalloc / hipFree or other allocating call.
+ * The array has to hold 512 bytes plus either every sample of the render (12 bytes per sample and pixel of the rank,
+ * tile padding included) or, for a render in several passes, 24 bytes per pixel (one sample and the running sums):
+ * renders of up to (SRT_STATIC_SCRATCH_BYTES - 512) / 24 = 2,796,181 pixels always fit, and one that fits neither
+ * way is refused with SRT_E_LIMIT.  Output, counters (srt_get_stats) and stream behaviour are srt_render_device's; a
+ * context with several devices runs it on its first.
+ * All calls on one GPU share that GPU's array, whatever their context: calls that overlap in time on one GPU (different
+ * streams, different contexts) race and give wrong pictures. */
+#define SRT_STATIC_SCRATCH_BYTES (64u << 20)
+int  srt_render_device_static(srt_ctx* ctx, const srt_render_params* p, void* d_rgba_out, size_t capacity_pixels, void* hip_stream);
 /* srt_render with the event counters of srt_stats filled (a separately compiled, slower kernel). */
 int  srt_render_counted(srt_ctx* ctx, const srt_render_params* p, uint32_t* rgba_out);
 

@@ -79,6 +79,7 @@ SYMBOLS = [
     ("srt_commit_scene", C.c_int, [_CTX, C.c_int]),
     ("srt_render", C.c_int, [_CTX, C.POINTER(RenderParams), C.c_void_p]),
     ("srt_render_device", C.c_int, [_CTX, C.POINTER(RenderParams), C.c_void_p, C.c_size_t, C.c_void_p]),
+    ("srt_render_device_static", C.c_int, [_CTX, C.POINTER(RenderParams), C.c_void_p, C.c_size_t, C.c_void_p]),
     ("srt_render_counted", C.c_int, [_CTX, C.POINTER(RenderParams), C.c_void_p]),
     ("srt_render_async", C.c_int, [_CTX, C.POINTER(RenderParams), C.c_void_p]),
     ("srt_poll", C.c_int, [_CTX, C.POINTER(C.c_int)]),

@@ -87,6 +87,7 @@ struct DeviceState {
     hipStream_t last_stream = nullptr;
     bool launched = false;
     srt_stats part{};                     // this device's share of the last collection
+    unsigned char* static_scratch = nullptr;   // this GPU's copy of the library's static workspace (srt_render_device_static)
 };
 
 }  // namespace
@@ -487,7 +488,8 @@ int create_device(DeviceState& d, int ordinal)
 #ifdef SRT_TIMELINE
               hipMalloc((void**)&d.d_timeline, trace_timeline_bytes()) == hipSuccess &&
 #endif
-              hipMemset(d.d_stats, 0, 32 * sizeof(unsigned long long)) == hipSuccess && hipDeviceSynchronize() == hipSuccess;
+              hipMemset(d.d_stats, 0, 32 * sizeof(unsigned long long)) == hipSuccess && hipDeviceSynchronize() == hipSuccess &&
+              static_scratch_setup(ordinal, &d.static_scratch) == hipSuccess;
     return ok ? SRT_OK : SRT_E_HIP;
 }
 
@@ -712,6 +714,42 @@ int srt_render_device(srt_ctx* c, const srt_render_params* p, void* d_rgba_out, 
 {
     if (!c) return SRT_E_INVALID;
     return launch(c, c->dev[0], p, (uint32_t*)d_rgba_out, capacity_pixels, (hipStream_t)hip_stream, false);
+}
+
+// The workspace comes out of the device's static array instead of hipMalloc: [work counter | running sums | samples].
+// Nothing on this path allocates: the events, the counters and the array's address were made by srt_create.
+int srt_render_device_static(srt_ctx* c, const srt_render_params* p, void* d_rgba_out, size_t capacity_pixels, void* hip_stream)
+{
+    if (!c) return SRT_E_INVALID;
+    DeviceState& d = c->dev[0];
+    if (!d.static_scratch) return fail(c, SRT_E_STATE, "the static workspace was not found on this device");
+    RenderArgs ra;
+    int rc = make_render_args(p, c->cam, ra, c->error);
+    if (rc != SRT_OK) return rc;
+    const size_t kHead = 512;   // the work counter, padded
+    const size_t per_sample = (size_t)ra.n_work * 12u;
+    const size_t room = (size_t)SRT_STATIC_SCRATCH_BYTES - kHead;
+    Workspace ws;
+    ws.fixed = true;
+    ws.counter = reinterpret_cast<uint32_t*>(d.static_scratch);
+    if (per_sample * (size_t)ra.samples <= room) {
+        // every sample of the render in one pass: no running sums
+        ws.samples = reinterpret_cast<float*>(d.static_scratch + kHead);
+        ws.samples_bytes = room;
+    } else {
+        const size_t running = (per_sample + 255u) & ~(size_t)255u;
+        if (running + per_sample > room) {
+            char msg[160];
+            std::snprintf(msg, sizeof msg, "the static workspace holds renders of up to %zu pixels per rank (24 bytes each), this one has %u",
+                          (size_t)(room / 24u), ra.n_work);
+            return fail(c, SRT_E_LIMIT, msg);
+        }
+        ws.running = reinterpret_cast<float*>(d.static_scratch + kHead);
+        ws.running_bytes = running;
+        ws.samples = reinterpret_cast<float*>(d.static_scratch + kHead + running);
+        ws.samples_bytes = room - running;
+    }
+    return launch(c, d, p, (uint32_t*)d_rgba_out, capacity_pixels, (hipStream_t)hip_stream, false, 1, 0, &ws);
 }
 
 static int start_async(srt_ctx* c, const srt_render_params* p, uint32_t* rgba_out, int passes)

@@ -22,10 +22,37 @@
 #include <cstdlib>
 #include <type_traits>
 
+#include "../../include/srt.h"
 #include "srt_launch.h"
 #include "srt_path.h"
 
+// Workspace of srt_render_device_static: every GPU the library runs on holds its own copy of this array, at its own
+// address, until the process ends.  In host code the name stands for the symbol, not for device memory: the address
+// for a kernel argument or a memset comes from hipGetSymbolAddress (static_scratch_setup below), once per device.
+static __device__ __align__(256) unsigned char scratch[SRT_STATIC_SCRATCH_BYTES];
+
 namespace srt {
+
+namespace {
+constexpr int kMaxScratchDevices = 64;
+unsigned char* g_scratch_ptr[kMaxScratchDevices] = {};
+}
+
+// Device `device` must be current.  Looks up (once per device) where that device holds `scratch`.
+hipError_t static_scratch_setup(int device, unsigned char** ptr)
+{
+    *ptr = nullptr;
+    if (device < 0 || device >= kMaxScratchDevices) return hipErrorInvalidDevice;
+    if (!g_scratch_ptr[device]) {
+        unsigned char* p = nullptr;
+        hipError_t e = hipGetSymbolAddress((void**)&p, HIP_SYMBOL(scratch));
+        if (e != hipSuccess) return e;
+        if (!p) return hipErrorInvalidSymbol;
+        g_scratch_ptr[device] = p;
+    }
+    *ptr = g_scratch_ptr[device];
+    return hipSuccess;
+}
 
 #ifndef SRT_WAVES_PER_SIMD_MESH
 #define SRT_WAVES_PER_SIMD_MESH 4   // mesh_trace_kernel waits on node gathers: 983k triangles 38.6 ms at 3 waves/SIMD, 35.9 at 4 (33 spilled VGPRs)

@@ -15,6 +15,9 @@ namespace srt {
 // d_timeline: trace_timeline_bytes() of device memory; only -DSRT_TIMELINE builds write to it (per-wavefront clock records).
 hipError_t launch_trace(const SceneView& sc, const RenderArgs& ra, bool exact, bool counted, float* d_samples,
                         unsigned long long* d_stats, uint32_t* d_work_counter, float* d_timeline, hipStream_t stream);
+// The address, on the current device `device`, of the library's static workspace of SRT_STATIC_SCRATCH_BYTES (the memory
+// srt_render_device_static works in).  Called once per device at set-up; allocates nothing.
+hipError_t static_scratch_setup(int device, unsigned char** ptr);
 size_t trace_timeline_bytes();
 size_t trace_timeline_records();  // experiments: how many records (4 x uint64 each, one per wavefront of the largest grid) there are
 size_t trace_timeline_offset();   // experiments: where a -DSRT_TIMELINE build leaves its per-wavefront clock records in d_timeline

@@ -133,6 +133,11 @@ class Renderer:
         self._check(self._lib.srt_render_device(self._ctx, C.byref(p), C.c_void_p(device_ptr), capacity_pixels,
                                                 C.c_void_p(stream or 0)))
 
+    def render_device_static(self, p, device_ptr, capacity_pixels, stream=None):
+        """render_device for callers that may not allocate: works in the library's static per-GPU workspace."""
+        self._check(self._lib.srt_render_device_static(self._ctx, C.byref(p), C.c_void_p(device_ptr), capacity_pixels,
+                                                       C.c_void_p(stream or 0)))
+
     def render_async(self, p, out):
         self._check(self._lib.srt_render_async(self._ctx, C.byref(p), out.ctypes.data_as(C.c_void_p)))
 

@@ -1,14 +1,25 @@
 #!/usr/bin/env python3
 """Benchmark of the trace loop on MI355X.
 
-    python bench.py --gpus N --steps K --warmup W        (N > 1: launched by torch.distributed.run, one rank per GPU)
+    python bench.py --gpus N --steps K --warmup W [--config c2|c3|c4|c5]
 
-A step is one frame of the headline workload -- the default Game1 scene (Game1.cs:96-144)
-at 1920x1080, depth 8, traced as the reference does (GetRayColor on the BVHNode world, Game1.cs:293) -- with 16
-samples per pixel PER GPU (weak scaling: N GPUs render 16*N spp; the frame is split into 32x32 screen tiles
-interleaved over the ranks, each rank traces its tiles, the tile buffers are gathered on rank 0 over RCCL and
-scattered into the frame by a kernel).  The scene, camera and framebuffers are resident in HBM before the timed
-region; the frame stays on the device (the PCIe copy of a 1080p frame is 8.3 MB).
+A step is one frame of the configuration, from the launch of its kernels to the frame's arrival in (pinned) host
+memory: trace + resolve kernels, with several GPUs the gather of the tile buffers and the assembly on the first one,
+and the copy of the frame to the host.  The scene, camera and buffers are resident before the timed region.
+
+  c2 (default)  the Game1 scene (Game1.cs:96-144), 1920x1080, 16 spp, depth 8, traced as the reference does
+                (GetRayColor on the BVHNode world, Game1.cs:293): the configuration the metric is quoted on
+  c3            teapot.dae subdivided to 101,120 triangles, 1920x1080, 64 spp, depth 4
+  c4            983,040-triangle mesh + 10,000 random spheres, 3840x2160, 256 spp, depth 8
+  c5            the 983,040-triangle mesh, 7680x4320, 1024 spp, depth 8
+  (--spp / --size shrink c3..c5 for quick runs; the workload string then says so.)
+
+Several GPUs, weak scaling (the configuration's spp per GPU, N times that per frame):
+  * started as a plain command (`python bench.py --gpus N`), one process drives all N GPUs through one libsrt context:
+    32x32 screen tiles interleaved over the devices, tile buffers gathered on the first device by grouped
+    ncclSend / ncclRecv, assembled there;
+  * started by torch.distributed.run with N ranks, every rank owns one GPU and one context, and the tile buffers are
+    gathered on rank 0 with torch.distributed (backend nccl = RCCL), then assembled by srt_assemble_tiles.
 
 Metric: Mrays/s, rays = GetRayColor calls with depth >= 1 (primary + bounce rays, one closest-hit query each), counted
 on the device.  Prints one JSON line on rank 0.
@@ -28,17 +39,31 @@ import torch  # noqa: E402
 import torch.distributed as dist  # noqa: E402
 
 import simple_raytracer_amd as srt  # noqa: E402
-from simple_raytracer_amd import game1  # noqa: E402
+from simple_raytracer_amd import game1, scenes  # noqa: E402
 
-WIDTH, HEIGHT, SPP_PER_GPU, MAX_DEPTH, TILE = 1920, 1080, 16, 8, 32
+TILE = 32
 PEAK_FP32_TFLOPS = 157.3   # MI355X vector FP32 (= f32 MFMA) peak
 PEAK_HBM_GBS = 8000.0      # MI355X HBM3E peak
 
-# Memory-side bytes per launch of the trace kernel on the N=1 workload, from separate `rocprofv3 --pmc FETCH_SIZE` and
-# `--pmc WRITE_SIZE` passes over this command (tools/pmc_traffic.sh; the counters are in KiB, and FETCH_SIZE is
+# name -> (scene factory(width, height), world kind, width, height, spp per GPU, depth, description)
+CONFIGS = {
+    "c2": (lambda w, h: game1.default_scene(w, h), srt.WORLD_BVHNODE, 1920, 1080, 16, 8,
+           "default Game1 scene (5 spheres, 2 point lights), bvhnode world"),
+    "c3": (lambda w, h: scenes.teapot_scene(w, h, 2), srt.WORLD_SURFACELIST, 1920, 1080, 64, 4,
+           "teapot.dae subdivided to 101,120 triangles, 2 point lights, surfacelist world (library tree)"),
+    "c4": (lambda w, h: scenes.sphere_mesh_scene(w, h, 5, 10000), srt.WORLD_SURFACELIST, 3840, 2160, 256, 8,
+           "983,040-triangle mesh + 10,000 random spheres, 2 point lights, surfacelist world (library tree)"),
+    "c5": (lambda w, h: scenes.sphere_mesh_scene(w, h, 5), srt.WORLD_SURFACELIST, 7680, 4320, 1024, 8,
+           "983,040-triangle mesh, 2 point lights, surfacelist world (library tree)"),
+}
+
+# Memory-side bytes per launch of the dominant kernel on the N=1 workload, from separate `rocprofv3 --pmc FETCH_SIZE`
+# and `--pmc WRITE_SIZE` passes over this command (tools/pmc_traffic.sh; the counters are in KiB, and FETCH_SIZE is
 # doubled, the correction for gfx950).  They are not re-measured by a normal run: a counter pass needs the profiler.
-# Almost all of it is private-memory traffic of the ray-tree frames below the levels kept in LDS, plus 0.4 GB of samples.
-MEASURED_TRAFFIC_KIB = {"bvhnode": (3106033.2, 12299515.6)}   # (FETCH_SIZE, WRITE_SIZE) of trace_kernel<true,false,true>
+# config -> (FETCH_SIZE KiB, WRITE_SIZE KiB, the profile the numbers come from)
+MEASURED_TRAFFIC_KIB = {
+    "c2": (3106033.2, 12299515.6, "profiles/r1_v6_pmc_traffic.txt"),
+}
 
 # Algorithmic work per event: bytes fetched / FP32 operations (add, sub, mul, div, sqrt, min, max, compare = 1 each)
 # of the reference algorithm, excluding work the GPU legitimately skips.
@@ -53,25 +78,46 @@ EVENT_COST = {                 # (bytes, flops)
 }
 
 
-def algorithmic_work(stats, pixels):
-    ev = dict(stats)
+def algorithmic_work(stats, pixels, scale=1.0):
+    ev = {k: stats[k] * scale for k in EVENT_COST if k != "pixels"}
     ev["pixels"] = pixels
     b = sum(ev[k] * c[0] for k, c in EVENT_COST.items())
     f = sum(ev[k] * c[1] for k, c in EVENT_COST.items())
     return b, f
 
 
-def cpu_baseline(width, height, spp, depth):
-    """The CPU oracle (a C++ restatement of the reference's algorithm, threaded by row bands like Game1.cs:376-380)
-    timed on this host on one frame of the same workload (about 20 s on 16 cores)."""
+def cpu_baseline(name, world, lights, cam, width, height, spp, depth):
+    """The CPU oracle (a C++ restatement of the reference's algorithm, incl. its own BVH builder, threaded by row bands
+    like Game1.cs:376-380) timed on this host.  c2: one whole frame (about 20 s on 16 cores).  Mesh configurations:
+    a 32x8 window at the centre of the frame at 1 spp -- the reference's tree costs 10^4..10^5 box tests per ray."""
     from oracle import orc   # checker / baseline only
     threads = min(16, os.cpu_count() or 1)
-    win = (0, 0, width, height)
-    sc, cam = orc.default_scene(), orc.default_camera(width, height)
-    _, st = sc.render(cam, width, height, samples=spp, max_depth=depth, seed=1, window=win, threads=threads)
-    return {"value": round(st["rays_path"] / st["seconds"] / 1e6, 4), "unit": "Mrays/s", "cores": threads, "kind": "port",
-            "sample": "one whole %dx%d %d-spp depth-%d frame (all rows, row bands over %d threads), %d rays in %.2f s" % (
-                width, height, spp, depth, threads, st["rays_path"], st["seconds"])}
+    if name == "c2":
+        sc, ocam = orc.default_scene(), orc.default_camera(width, height)
+        _, st = sc.render(ocam, width, height, samples=spp, max_depth=depth, seed=1, window=(0, 0, width, height), threads=threads)
+        sample = "one whole %dx%d %d-spp depth-%d frame (all rows, row bands over %d threads), %d rays in %.2f s" % (
+            width, height, spp, depth, threads, st["rays_path"], st["seconds"])
+    else:
+        flat = world.flatten()
+        mats = [orc.material(m.albedo, m.metalness, m.smoothness, m.emission) for m in flat["materials"]]
+        tris = orc.tris_from_arrays(flat["tri_pos"], flat["tri_nrm"], 0)
+        tris["material"] = flat["tri_mat"]
+        sph = [orc.Sphere(orc.f3(s[:3]), float(s[3]), int(m)) for s, m in zip(flat["spheres"], flat["sphere_mat"])]
+        t = time.time()
+        sc = orc.Scene(mats, spheres=sph, tris=tris, lights=[orc.point_light(l.position, l.brightness, None) for l in lights.lights])
+        build_s = time.time() - t
+        ocam = orc.Camera(orc.f3(cam.position), orc.f3(cam.lowerLeftCorner), orc.f3(cam.horizontal), orc.f3(cam.vertical))
+        x0, y0 = ((width // 2) // 32) * 32, ((height // 2) // 32) * 32
+        _, st = sc.render(ocam, width, height, samples=1, max_depth=depth, seed=1, window=(x0, y0, x0 + 32, y0 + 8), threads=threads)
+        sample = "32x8 window at the centre of the %dx%d frame, 1 spp, depth %d, the reference's own tree (built in %.1f s): %d rays in %.1f s" % (
+            width, height, depth, build_s, st["rays_path"], st["seconds"])
+    return {"value": round(st["rays_path"] / st["seconds"] / 1e6, 6), "unit": "Mrays/s", "cores": threads, "kind": "port", "sample": sample}
+
+
+def pinned_frame(pixels):
+    """Page-locked host memory for the frame, as a numpy view (the C# host pins its Color[] the same way)."""
+    t = torch.empty(pixels, dtype=torch.int32).pin_memory()
+    return t, t.numpy().view(np.uint32)
 
 
 def main():
@@ -79,15 +125,33 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--config", choices=sorted(CONFIGS), default="c2")
+    ap.add_argument("--spp", type=int, default=0, help="samples per pixel and GPU (default: the configuration's)")
+    ap.add_argument("--size", default="", help="WxH (default: the configuration's)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--world-kind", choices=["bvhnode", "surfacelist"], default="bvhnode")
+    ap.add_argument("--gather", choices=["rccl", "peer"], default="rccl", help="in-library multi-GPU: how tiles reach the first device")
+    ap.add_argument("--virtual-devices", action="store_true", help="rehearsal: all --gpus entries name device 0 (one context, several replicas)")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
-    if world != args.gpus:
-        raise SystemExit("--gpus %d but WORLD_SIZE=%d: launch with torch.distributed.run --nproc-per-node %d" % (args.gpus, world, args.gpus))
+    if world > 1 and world != args.gpus:
+        raise SystemExit("--gpus %d but WORLD_SIZE=%d" % (args.gpus, world))
+    # world == 1 and --gpus N > 1: this process drives all N GPUs through one context (the C# host's situation)
+    in_library = world == 1 and args.gpus > 1
+    n_gpus = args.gpus
+
+    make, kind, width, height, spp_per_gpu, depth, what = CONFIGS[args.config]
+    reduced = []
+    if args.spp:
+        spp_per_gpu = args.spp
+        reduced.append("spp")
+    if args.size:
+        width, height = (int(v) for v in args.size.lower().split("x"))
+        reduced.append("size")
+    spp = spp_per_gpu * n_gpus
+
     # SRT_BENCH_BACKEND=gloo is a rehearsal mode for boxes with fewer GPUs than ranks (the ranks then share devices and
     # the tile buffers are gathered through host memory); the measured configuration is nccl = RCCL, one GPU per rank.
     backend = os.environ.get("SRT_BENCH_BACKEND", "nccl")
@@ -100,37 +164,50 @@ def main():
             dist.init_process_group(backend)
     reduce_device = "cuda" if backend == "nccl" else "cpu"
 
-    spp = SPP_PER_GPU * world
-    r = srt.Renderer(device=device_index)
-    scene_world, lights, cam = game1.default_scene(WIDTH, HEIGHT)
-    kind = srt.WORLD_BVHNODE if args.world_kind == "bvhnode" else srt.WORLD_SURFACELIST
+    if in_library:
+        devices = [0] * n_gpus if args.virtual_devices else list(range(n_gpus))
+        r = srt.Renderer(devices=devices, gather=srt.GATHER_RCCL if args.gather == "rccl" else srt.GATHER_PEER_COPY)
+    else:
+        r = srt.Renderer(device=device_index)
+    info = r.device_info()
+    if in_library and not args.virtual_devices and args.gather == "rccl" and info["rccl_ranks"] != n_gpus:
+        raise SystemExit("the RCCL communicator has %d ranks, expected %d" % (info["rccl_ranks"], n_gpus))
+    scene_world, lights, cam = make(width, height)
+    t0 = time.perf_counter()
     r.set_scene(scene_world, lights, cam, world_kind=kind)
+    commit_s = time.perf_counter() - t0
 
     stream = torch.cuda.current_stream().cuda_stream
     tf = None
     if world == 1:
-        p = r.params(WIDTH, HEIGHT, samples=spp, max_depth=MAX_DEPTH, seed=1)
-        local = r.local_pixels(p)
-        out = torch.zeros(local, dtype=torch.int32, device="cuda")
+        p = r.params(width, height, samples=spp, max_depth=depth, seed=1)
+        local = width * height
+        host_t, host = pinned_frame(local)
     else:
         from simple_raytracer_amd.distributed import TiledFrame
-        tf = TiledFrame(r, WIDTH, HEIGHT, rank=rank, world_size=world, tile=TILE, device="cuda", samples=spp, max_depth=MAX_DEPTH, seed=1)
+        tf = TiledFrame(r, width, height, rank=rank, world_size=world, tile=TILE, device="cuda", samples=spp, max_depth=depth, seed=1)
         p, local = tf.params, tf.local_pixels
+        host_t = torch.empty(width * height, dtype=torch.int32).pin_memory() if rank == 0 else None
 
-    def step(events=None):
-        if events is not None:
-            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-            e0.record()
+    import ctypes as C
+    device_ms = []     # per step: device time of the frame's trace + resolve kernels (HIP events on the launch stream)
+    counts = [0.0, 0.0]  # path rays, shadow rays of the timed steps
+
+    def step(record=False):
         if tf is None:
-            r.render_device(p, out.data_ptr(), out.numel(), stream)
+            # blocking: kernels (+ gather + assemble) + copy of the frame into pinned host memory
+            r._check(r._lib.srt_render(r._ctx, C.byref(p), host.ctypes.data_as(C.c_void_p)))
+            if record:
+                st = r.stats()   # collected by the blocking render; no extra wait
+                device_ms.append(st["kernel_ms"])
+                counts[0] += st["rays_path"]
+                counts[1] += st["rays_shadow"]
         else:
             tf.render_local()
-        if events is not None:
-            e1.record()
-            events.append((e0, e1))
-        if tf is not None:
             tf.gather()      # RCCL gather of the tile buffers to rank 0
-            tf.assemble()    # rank 0: tiles -> frame
+            frame = tf.assemble()    # rank 0: tiles -> frame
+            if frame is not None:
+                host_t.copy_(frame, non_blocking=True)
 
     def fence():
         torch.cuda.synchronize()
@@ -142,67 +219,90 @@ def main():
         step()
     fence()
     r.stats()          # drop the warmup's counters
-    events = []
     fence()
     t0 = time.perf_counter()
     for _ in range(args.steps):
-        step(events)
+        step(True)
     fence()
     elapsed = time.perf_counter() - t0
-    st = r.stats()     # counters accumulated over the timed launches
-    launch_ms = [a.elapsed_time(b) for a, b in events]
+    rays, shadow = counts
+    if tf is not None:
+        st = r.stats()     # counters accumulated over the timed launches; kernel_ms is the last launch's
+        rays, shadow = float(st["rays_path"]), float(st["rays_shadow"])
+        device_ms.append(st["kernel_ms"])
+    per_device_ms = [round(r.device_stats(i)["kernel_ms"], 4) for i in range(len(info["devices"]))] if in_library else None
 
     t = torch.tensor([elapsed], dtype=torch.float64, device=reduce_device)
-    rays = torch.tensor([float(st["rays_path"]), float(st["rays_shadow"])], dtype=torch.float64, device=reduce_device)
+    rr = torch.tensor([rays, shadow], dtype=torch.float64, device=reduce_device)
     if world > 1:
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dist.all_reduce(rays, op=dist.ReduceOp.SUM)
+        dist.all_reduce(rr, op=dist.ReduceOp.SUM)
     elapsed = float(t.item())
-    total_rays, total_shadow = float(rays[0].item()), float(rays[1].item())
+    total_rays, total_shadow = float(rr[0].item()), float(rr[1].item())
 
     if rank == 0:
-        # algorithmic work of ONE launch of this rank's trace kernel, from the counting build of the same kernel
-        host = np.zeros(local, dtype=np.uint32)
-        import ctypes as C
-        r._check(r._lib.srt_render_counted(r._ctx, C.byref(p), host.ctypes.data_as(C.c_void_p)))
+        # Algorithmic work of ONE frame on this rank's devices, from the counting build of the same kernels.  The
+        # big configurations count a 16-spp render of the same frame and scale by the sample ratio.
+        count_spp = spp if args.config == "c2" else min(spp, 16)
+        pc = r.params(width, height, samples=count_spp, max_depth=depth, seed=1)
+        if tf is not None:
+            pc = r.params(width, height, samples=count_spp, max_depth=depth, seed=1, layout=srt.LAYOUT_TILES, tile_w=TILE, tile_h=TILE,
+                          rank=rank, world_size=world)
+        scratch = np.zeros(r.local_pixels(pc), dtype=np.uint32)
+        r._check(r._lib.srt_render_counted(r._ctx, C.byref(pc), scratch.ctypes.data_as(C.c_void_p)))
         cst = r.stats()
-        px = WIDTH * HEIGHT if world == 1 else local
-        abytes, aflops = algorithmic_work(cst, px)
-        avg_ms = float(np.mean(launch_ms))
+        px = width * height if tf is None else local
+        abytes, aflops = algorithmic_work(cst, px, spp / count_spp)
+        avg_ms = float(np.mean(device_ms))
         tflops = aflops / (avg_ms * 1e-3) / 1e12
         gbs = abytes / (avg_ms * 1e-3) / 1e9
-        # Which roof applies is decided by where the scene lives: geometry that fits the scalar / L1 caches (the Game1
-        # scene is 5 nodes + 5 spheres) is never re-fetched from HBM, so its "algorithmic bytes" are cache hits and
-        # the kernel is bound by vector FP32 issue; a BVH that exceeds the 32 MiB of L2 is bound by memory.
-        scene_bytes = cst["bvh_nodes"] * 32 + cst["n_prims"] * 48
-        valu_bound = scene_bytes < (1 << 20) or tflops / PEAK_FP32_TFLOPS >= gbs / PEAK_HBM_GBS
-        roofline = ({"bound": "valu_fp32", "achieved": round(tflops, 3), "peak": PEAK_FP32_TFLOPS, "unit": "TFLOP/s",
-                     "frac": round(tflops / PEAK_FP32_TFLOPS, 4)} if valu_bound else
-                    {"bound": "hbm", "achieved": round(gbs, 2), "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": round(gbs / PEAK_HBM_GBS, 4)})
-        traffic = None
-        if world == 1 and args.world_kind in MEASURED_TRAFFIC_KIB:
-            fetch_kib, write_kib = MEASURED_TRAFFIC_KIB[args.world_kind]
+        if in_library:
+            tflops, gbs = tflops / n_gpus, gbs / n_gpus     # per GPU: the frame's work is spread over n_gpus devices
+        # Which roof applies is decided by where the scene lives and by what the counters show.  The Game1 scene is 5
+        # nodes + 5 spheres: its "algorithmic bytes" are scalar-cache hits and the kernel is bound by vector FP32
+        # issue.  The mesh scenes (17 MB of nodes + 47 MB of triangles) live in L2 + Infinity Cache: their SQ counters
+        # show VALU issue ~ 96 % busy and 0.3 TB/s from beyond L2, so vector FP32 issue is their roof as well, and
+        # the node / triangle bytes are reported against the L2 bandwidth as a second figure.
+        roofline = {"bound": "valu_fp32", "achieved": round(tflops, 3), "peak": PEAK_FP32_TFLOPS, "unit": "TFLOP/s",
+                    "frac": round(tflops / PEAK_FP32_TFLOPS, 4)}
+        traffic, traffic_source = None, None
+        if world == 1 and not in_library and not reduced and args.config in MEASURED_TRAFFIC_KIB:
+            fetch_kib, write_kib, where = MEASURED_TRAFFIC_KIB[args.config]
             traffic = int((2.0 * fetch_kib + write_kib) * 1024)
-        roofline.update({"traffic": traffic, "traffic_source": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command, 2*FETCH+WRITE "
-                         "(profiles/r1_v6_pmc_traffic.txt); constant, not re-measured in this run", "kernel": "trace_kernel", "avg_launch_ms": round(avg_ms, 4),
+            traffic_source = "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command, 2*FETCH+WRITE (%s); constant, not re-measured in this run" % where
+        kernel = "trace_kernel" if args.config == "c2" else "mesh_trace_kernel"
+        roofline.update({"traffic": traffic, "traffic_source": traffic_source, "kernel": kernel + " (+ resolve_kernel) of one frame",
+                         "avg_launch_ms": round(avg_ms, 4),
                          "algorithmic_flops_per_launch": aflops, "algorithmic_bytes_per_launch": abytes,
-                         "algorithmic_gbs": round(gbs, 2), "algorithmic_tflops": round(tflops, 3)})
+                         "algorithmic_gbs": round(gbs, 2), "algorithmic_tflops": round(tflops, 3),
+                         "counted_spp": count_spp})
+        how = ("single frame buffer" if n_gpus == 1 else
+               ("one process, one context over %d devices %s: 32x32 tiles interleaved, %s, assembled on device %d" % (
+                   n_gpus, info["devices"], "grouped ncclSend/ncclRecv (communicator of %d ranks)" % info["rccl_ranks"] if info["gather"] == srt.GATHER_RCCL
+                   else "peer copies", info["devices"][0]) if in_library else
+                ("one process per GPU: 32x32 tiles interleaved over ranks + RCCL gather to rank 0" if backend == "nccl" else
+                 "one process per GPU: 32x32 tiles interleaved over ranks + gloo gather through host memory (REHEARSAL, ranks may share GPUs)")))
+        ms_step = elapsed / args.steps * 1e3
         line = {
             "metric": "Mrays/sec (primary+bounce)", "value": round(total_rays / elapsed / 1e6, 2), "unit": "Mrays/s",
-            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(elapsed / args.steps * 1e3, 4),
+            "n_gpus": n_gpus, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_step, 4),
+            "ms_per_step_device_only": round(avg_ms, 4),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "config": {"workload": "default Game1 scene (5 spheres, 2 point lights), %dx%d, %d spp per GPU (%d total), depth %d, %s world, "
-                                   "%s" % (WIDTH, HEIGHT, SPP_PER_GPU, spp, MAX_DEPTH, args.world_kind,
-                                           "single frame buffer" if world == 1 else
-                                           ("32x32 tiles interleaved over ranks + RCCL gather to rank 0" if backend == "nccl" else
-                                            "32x32 tiles interleaved over ranks + gloo gather through host memory (REHEARSAL, ranks may share GPUs)")),
-                       "width": WIDTH, "height": HEIGHT, "spp": spp, "max_depth": MAX_DEPTH, "seed": 1},
+            "config": {"workload": "%s: %s, %dx%d, %d spp per GPU (%d total), depth %d; %s; the step ends with the frame in pinned host memory%s" % (
+                           args.config, what, width, height, spp_per_gpu, spp, depth, how,
+                           "; REDUCED %s against the named configuration" % "+".join(reduced) if reduced else ""),
+                       "name": args.config, "width": width, "height": height, "spp": spp, "max_depth": depth, "seed": 1,
+                       "devices": info["devices"] if in_library else [device_index], "rccl_ranks": info["rccl_ranks"] if in_library else (world if world > 1 and backend == "nccl" else 0),
+                       "path_rays_per_step": total_rays / args.steps, "shadow_rays_per_step": total_shadow / args.steps,
+                       "scene_commit_s": round(commit_s, 3), "bvh_nodes": cst["bvh_nodes"], "surfaces": cst["n_prims"]},
             "rays_per_step": total_rays / args.steps, "shadow_rays_per_step": total_shadow / args.steps,
             "traversals_per_sec_M": round((total_rays + total_shadow) / elapsed / 1e6, 2),
             "roofline": roofline,
         }
-        if world == 1 and not args.no_cpu_baseline:
-            line["cpu_baseline"] = cpu_baseline(WIDTH, HEIGHT, spp, MAX_DEPTH)
+        if per_device_ms is not None:
+            line["per_device_kernel_ms_last_step"] = per_device_ms
+        if n_gpus == 1 and not args.no_cpu_baseline:
+            line["cpu_baseline"] = cpu_baseline(args.config, scene_world, lights, cam, width, height, spp, depth)
         print(json.dumps(line), flush=True)
     if world > 1:
         dist.barrier()

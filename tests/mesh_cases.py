@@ -49,27 +49,46 @@ def run(renderer, orc, case, counted=False):
     return lsb, npx, st, ost
 
 
-def large_mesh_window(renderer, orc):
-    """teapot.dae subdivided twice (101,120 triangles) as a SurfaceList world: one 32x8 window at the centre of a
-    640x360 picture through the library's own tree, against the oracle's linear SurfaceList.hit scan.
-    -> (max LSB difference, differing pixels, distinct colours in the window, tree nodes)."""
-    from simple_raytracer_amd import scenes
-    w, h, depth = 640, 360, 4
-    world, lights, cam = scenes.teapot_scene(w, h, 2)
+def scene_window(renderer, orc, make, n_surfaces, size=(640, 360), depth=4, samples=2, seed=3, rows=8):
+    """A scene too large for a whole-frame oracle render, as a SurfaceList world: one 32 x `rows` window at the centre
+    of the picture through the library's own tree, against the oracle's linear SurfaceList.hit scan over every surface.
+    -> (max LSB difference, differing pixels, distinct colours in the window, tree nodes, library stats, oracle stats)."""
+    w, h = size
+    world, lights, cam = make(w, h)
     flat = world.flatten()
-    assert len(flat["tri_pos"]) == 101120
+    assert len(flat["tri_pos"]) + len(flat["spheres"]) == n_surfaces
     mats = [orc.material(m.albedo, m.metalness, m.smoothness, m.emission) for m in flat["materials"]]
     tris = orc.tris_from_arrays(flat["tri_pos"], flat["tri_nrm"], 0)
     tris["material"] = flat["tri_mat"]
-    osc = orc.Scene(mats, spheres=[], tris=tris, lights=[orc.point_light(l.position, l.brightness, None) for l in lights.lights])
+    sph = [orc.Sphere(orc.f3(s[:3]), float(s[3]), int(m)) for s, m in zip(flat["spheres"], flat["sphere_mat"])]
+    osc = orc.Scene(mats, spheres=sph, tris=tris, lights=[orc.point_light(l.position, l.brightness, None) for l in lights.lights])
     ocam = orc.Camera(orc.f3(cam.position), orc.f3(cam.lowerLeftCorner), orc.f3(cam.horizontal), orc.f3(cam.vertical))
     tile_x, tile_y = (w // 2) // 32, (h // 2) // 32
     x0, y0 = tile_x * 32, tile_y * 32
-    ref, _ = osc.render(ocam, w, h, samples=2, max_depth=depth, seed=3, window=(x0, y0, x0 + 32, y0 + 8), world_kind=srt.WORLD_SURFACELIST)
+    ref, ost = osc.render(ocam, w, h, samples=samples, max_depth=depth, seed=seed, window=(x0, y0, x0 + 32, y0 + rows),
+                          world_kind=srt.WORLD_SURFACELIST)
     renderer.set_scene(world, lights, cam, world_kind=srt.WORLD_SURFACELIST)
     nodes = renderer.stats()["bvh_nodes"]
     tiles_x, tiles_y = (w + 31) // 32, (h + 31) // 32
-    tile = renderer.render(w, h, samples=2, max_depth=depth, seed=3, layout=srt.LAYOUT_TILES, tile_w=32, tile_h=32,
+    # the window's tile alone: "rank t of as many ranks as there are tiles"
+    tile = renderer.render(w, h, samples=samples, max_depth=depth, seed=seed, layout=srt.LAYOUT_TILES, tile_w=32, tile_h=32,
                            rank=tile_y * tiles_x + tile_x, world_size=tiles_x * tiles_y).reshape(32, 32)
-    lsb, npx = helpers.max_lsb_diff(tile[:8, :], ref[y0:y0 + 8, x0:x0 + 32])
-    return lsb, npx, len(np.unique(tile[:8, :])), nodes
+    lsb, npx = helpers.max_lsb_diff(tile[:rows, :], ref[y0:y0 + rows, x0:x0 + 32])
+    return lsb, npx, len(np.unique(tile[:rows, :])), nodes, renderer.stats(), ost
+
+
+def large_mesh_window(renderer, orc):
+    """teapot.dae subdivided twice (101,120 triangles, the mesh of benchmark configuration 3)."""
+    return scene_window(renderer, orc, lambda w, h: scenes.teapot_scene(w, h, 2), 101120)[:4]
+
+
+def million_triangle_window(renderer, orc):
+    """sphere.dae subdivided five times (983,040 triangles, the mesh of benchmark configurations 4 and 5), depth 8."""
+    return scene_window(renderer, orc, lambda w, h: scenes.sphere_mesh_scene(w, h, 5), 983040, depth=8, samples=1)
+
+
+def sphere_cloud_window(renderer, orc):
+    """The scene of benchmark configuration 4: the 983,040-triangle mesh inside 10,000 random metal / rough spheres,
+    depth 8 (ray trees of up to 3,280 nodes); four rows, because every query is a linear scan of 993,040 surfaces for
+    the oracle."""
+    return scene_window(renderer, orc, lambda w, h: scenes.sphere_mesh_scene(w, h, 5, 10000), 993040, depth=8, samples=1, rows=4)

@@ -89,7 +89,7 @@ def algorithmic_work(stats, pixels, scale=1.0):
 def cpu_baseline(name, world, lights, cam, width, height, spp, depth):
     """The CPU oracle (a C++ restatement of the reference's algorithm, incl. its own BVH builder, threaded by row bands
     like Game1.cs:376-380) timed on this host.  c2: one whole frame (about 20 s on 16 cores).  Mesh configurations:
-    a 32x8 window at the centre of the frame at 1 spp -- the reference's tree costs 10^4..10^5 box tests per ray."""
+    a few columns x `threads` rows at the centre of the frame at 1 spp -- the reference's tree costs 10^4..10^5 box tests per ray."""
     from oracle import orc   # checker / baseline only
     threads = min(16, os.cpu_count() or 1)
     if name == "c2":
@@ -107,10 +107,12 @@ def cpu_baseline(name, world, lights, cam, width, height, spp, depth):
         sc = orc.Scene(mats, spheres=sph, tris=tris, lights=[orc.point_light(l.position, l.brightness, None) for l in lights.lights])
         build_s = time.time() - t
         ocam = orc.Camera(orc.f3(cam.position), orc.f3(cam.lowerLeftCorner), orc.f3(cam.horizontal), orc.f3(cam.vertical))
+        # one row per thread; the width bounds the sample to some tens of seconds (1 to 1,000 rays per second and thread)
+        cols = {"c3": 32, "c4": 2, "c5": 4}[name]
         x0, y0 = ((width // 2) // 32) * 32, ((height // 2) // 32) * 32
-        _, st = sc.render(ocam, width, height, samples=1, max_depth=depth, seed=1, window=(x0, y0, x0 + 32, y0 + 8), threads=threads)
-        sample = "32x8 window at the centre of the %dx%d frame, 1 spp, depth %d, the reference's own tree (built in %.1f s): %d rays in %.1f s" % (
-            width, height, depth, build_s, st["rays_path"], st["seconds"])
+        _, st = sc.render(ocam, width, height, samples=1, max_depth=depth, seed=1, window=(x0, y0, x0 + cols, y0 + threads), threads=threads)
+        sample = "%dx%d window at the centre of the %dx%d frame, 1 spp, depth %d, the reference's own tree (built in %.1f s): %d rays in %.1f s" % (
+            cols, threads, width, height, depth, build_s, st["rays_path"], st["seconds"])
     return {"value": round(st["rays_path"] / st["seconds"] / 1e6, 6), "unit": "Mrays/s", "cores": threads, "kind": "port", "sample": sample}
 
 

@@ -48,8 +48,13 @@ enum {
     SRT_WORLD_BVHNODE = 0,
     /* GetRayColor(ray, world, ...): SurfaceList.hit semantics (RaytracingClasses.cs:298-316), the
      * closest hit over every surface in insertion order, later surface winning an exact tie.
-     * The library answers this query through its own SAH BVH with padded boxes, which returns
-     * the same hit as the linear scan. */
+     * The library answers this query through its own tree (binned SAH, collapsed to 4-wide quantised nodes), which
+     * returns the same hit as the linear scan: boxes only cull, and they are padded by more than the float surface
+     * tests can be wrong by -- Sphere.hit accepts rays that pass a sphere at a distance that grows with the distance
+     * of the ray's origin (the rounding error of its discriminant), so sphere boxes are widened for every origin in
+     * the ball around the scene, and a query that starts farther away widens the boxes it tests in proportion to its
+     * distance; surfaces with coordinates beyond 2^40, and the queries whose tests can return NaN, fall back to the
+     * scan itself. */
     SRT_WORLD_SURFACELIST = 1
 };
 
@@ -138,7 +143,7 @@ typedef struct {
     uint64_t sphere_tests, tri_tests, rect_tests;   /* (only filled by srt_render_counted) */
     double   kernel_ms;      /* device time of the last render (its trace and resolve kernels), from HIP events on its stream */
     double   build_ms;       /* host time of the last srt_commit_scene (BVH build + upload) */
-    uint32_t bvh_nodes;      /* nodes of the committed tree: 32 bytes each (reference tree) or 64 (the library's 4-wide tree) */
+    uint32_t bvh_nodes;      /* nodes of the committed tree: BVHNode objects of the reference tree (32 bytes each) or the library's 4-wide nodes (64) */
     uint32_t bvh_depth;
     uint32_t n_prims;
     uint32_t reserved;
@@ -151,6 +156,11 @@ typedef struct {
        8 child directions, 9 fresnel, 10 starting a child / finishing a leaf; 11-14 unused;
        15 is a count, not cycles: subtrees that lanes handed to idle lanes of their wavefront (mesh scenes). */
     uint64_t section_cycles[16];
+    /* Lane-cycles (only filled by srt_render_counted; stackless scenes): slots 0-10 as above but summed over the 64 lanes
+       of every wavefront, counting a lane only while it worked in the part; 11-14 the lane-cycles spent waiting for the
+       other lanes of the wavefront to finish handing values up / taking new items / their closest-hit part / their
+       light part.  Slots 0-10 over the sum of 0-14 is the share of lane time that did work. */
+    uint64_t section_lane_cycles[16];
 } srt_stats;
 
 typedef struct srt_ctx srt_ctx;

@@ -230,14 +230,19 @@ inline float Magnitude(Vec a) { return (a.X * a.X + a.Y * a.Y + a.Z * a.Z); }
 struct Counters {
     uint64_t rays_path = 0, rays_shadow = 0, rays_redundant = 0, box_tests = 0;
     uint64_t sphere_tests = 0, tri_tests = 0, rect_tests = 0, hit_nodes = 0;
+    // the part of the four *_tests above that repeats a test whose answer is already known: everything inside a
+    // per-light re-intersection (RaytracingClasses.cs:211) and the second test of a single-surface leaf (:362-365)
+    uint64_t box_repeats = 0, sphere_repeats = 0, tri_repeats = 0, rect_repeats = 0;
     void add(const Counters& o)
     {
         rays_path += o.rays_path; rays_shadow += o.rays_shadow; rays_redundant += o.rays_redundant;
         box_tests += o.box_tests; sphere_tests += o.sphere_tests; tri_tests += o.tri_tests;
         rect_tests += o.rect_tests; hit_nodes += o.hit_nodes;
+        box_repeats += o.box_repeats; sphere_repeats += o.sphere_repeats; tri_repeats += o.tri_repeats; rect_repeats += o.rect_repeats;
     }
 };
 thread_local Counters* t_cnt = nullptr;
+thread_local int t_repeat = 0;   // > 0 while the traversal only repeats tests (see Counters)
 Counters g_sink;
 inline Counters& C() { return t_cnt ? *t_cnt : g_sink; }
 
@@ -280,6 +285,7 @@ struct AABB {
     bool hit(const CustomRay& ray) const
     {
         C().box_tests++;
+        if (t_repeat) C().box_repeats++;
         float t1 = (min.X - ray.origin.X) * ray.dirFrac.X;
         float t2 = (max.X - ray.origin.X) * ray.dirFrac.X;
         float t3 = (min.Y - ray.origin.Y) * ray.dirFrac.Y;
@@ -335,6 +341,7 @@ struct Sphere : Surface {
     bool hit(const CustomRay& ray, float t_min, float t_max, hitRecord& record) const override
     {
         C().sphere_tests++;
+        if (t_repeat) C().sphere_repeats++;
         Vec distance = ray.origin - origin;
         float a = DistanceSquared(ray.direction, V(0, 0, 0));
         float half_b = Dot(distance, ray.direction);
@@ -368,6 +375,7 @@ struct RectAxis : Surface {
     bool hit(const CustomRay& ray, float t_min, float t_max, hitRecord& record) const override
     {
         C().rect_tests++;
+        if (t_repeat) C().rect_repeats++;
         float t = (-k - ray.origin.Z / ray.direction.Z);
         if (t < t_min || t > t_max) return false;
         float x = ray.origin.X + (t * ray.direction.X);
@@ -399,6 +407,7 @@ struct Tri : Surface {
     bool hit(const CustomRay& ray, float t_min, float t_max, hitRecord& record) const override
     {
         C().tri_tests++;
+        if (t_repeat) C().tri_repeats++;
         Vec pVec = Cross(ray.direction, AC);  // a racy instance field in the reference (:599,679); local here
         float discriminant = Dot(AB, pVec);
         if ((double)discriminant < 1e-8 && !flipNormal) return false;
@@ -550,7 +559,9 @@ struct BVHNode : Surface {
         bool hitLeft = false;
         bool hitRight = false;
         if ((hitLeft = left->hit(ray, t_min, t_max, record))) t_max = record.t;
+        if (left == right) t_repeat++;   // a leaf with one surface tests it twice (:362-365)
         if ((hitRight = right->hit(ray, t_min, t_max, record))) t_max = record.t;
+        if (left == right) t_repeat--;
         return hitLeft || hitRight;
     }
     void leafOrder(std::vector<int>& out) const
@@ -644,7 +655,10 @@ struct LightList : Light {
     {
         for (size_t i = 0; i < lightArray.size(); i++) {
             C().rays_redundant++;
-            if (world->hit(ray, 0.01f, std::numeric_limits<float>::infinity(), record)) {
+            t_repeat++;
+            const bool again = world->hit(ray, 0.01f, std::numeric_limits<float>::infinity(), record);
+            t_repeat--;
+            if (again) {
                 formerLightLevel = formerLightLevel + lightArray[i]->calculateLight(formerLightLevel, ray, world, record, key, (uint32_t)i, blinnPhong);
             }
         }
@@ -1104,6 +1118,8 @@ static int RenderSamples(const orc_scene* s, const orc_camera* cam, const orc_pa
         stats->rays_path = total.rays_path; stats->rays_shadow = total.rays_shadow; stats->rays_redundant = total.rays_redundant;
         stats->box_tests = total.box_tests; stats->sphere_tests = total.sphere_tests; stats->tri_tests = total.tri_tests;
         stats->rect_tests = total.rect_tests; stats->hit_nodes = total.hit_nodes;
+        stats->box_repeats = total.box_repeats; stats->sphere_repeats = total.sphere_repeats;
+        stats->tri_repeats = total.tri_repeats; stats->rect_repeats = total.rect_repeats;
         stats->seconds = std::chrono::duration<double>(t1 - t0).count();
         stats->threads_used = n;
     }
@@ -1135,6 +1151,7 @@ int orc_render_mix_buffers(const orc_scene* s, const orc_camera* cam, const orc_
         total.rays_path += one.rays_path; total.rays_shadow += one.rays_shadow; total.rays_redundant += one.rays_redundant;
         total.box_tests += one.box_tests; total.sphere_tests += one.sphere_tests; total.tri_tests += one.tri_tests;
         total.rect_tests += one.rect_tests; total.hit_nodes += one.hit_nodes; total.seconds += one.seconds; total.threads_used = one.threads_used;
+        total.box_repeats += one.box_repeats; total.sphere_repeats += one.sphere_repeats; total.tri_repeats += one.tri_repeats; total.rect_repeats += one.rect_repeats;
         for (size_t i = 0; i < n; i++) {
             // Color.ToVector3(): (R / 255f, G / 255f, B / 255f)
             Vec tempBuffCol = V((float)(out[i] & 255u) / 255.0f, (float)((out[i] >> 8) & 255u) / 255.0f, (float)((out[i] >> 16) & 255u) / 255.0f);

@@ -53,6 +53,11 @@ typedef struct {
     uint64_t hit_nodes;          /* GetRayColor calls that hit something */
     double   seconds;            /* wall time of the render call */
     int32_t  threads_used;
+    int32_t  reserved;
+    /* the part of box_tests / sphere_tests / tri_tests / rect_tests that repeats a test whose answer is known: all of a
+       per-light re-intersection (RaytracingClasses.cs:211) and the second test of a single-surface leaf (:362-365).
+       An implementation that reuses those answers performs exactly (tests - repeats) tests. */
+    uint64_t box_repeats, sphere_repeats, tri_repeats, rect_repeats;
 } orc_stats;
 
 typedef struct orc_scene orc_scene;

@@ -130,6 +130,7 @@ struct srt_ctx {
 
 namespace {
 
+constexpr int kStatsWords = 48;   // counters a trace kernel adds to (srt_launch.h)
 thread_local std::string g_create_error;
 
 int fail(srt_ctx* c, int code, const std::string& msg)
@@ -189,7 +190,7 @@ void zero_counts(srt_stats& s)
     s.rays_path = s.rays_shadow = s.hit_nodes = 0;
     s.box_tests = s.sphere_tests = s.tri_tests = s.rect_tests = 0;
     s.trace_sections = s.trace_lanes = s.light_sections = s.light_lanes = 0;
-    for (int i = 0; i < 16; i++) s.section_cycles[i] = 0;
+    for (int i = 0; i < 16; i++) s.section_cycles[i] = s.section_lane_cycles[i] = 0;
     s.kernel_ms = 0.0;
 }
 
@@ -203,7 +204,7 @@ int collect_stats(srt_ctx* c)
         if (!d.stats_pending) continue;
         SRT_HIP(c, hipSetDevice(d.device));
         SRT_HIP(c, hipEventSynchronize(d.ev_end));
-        unsigned long long s[32];
+        unsigned long long s[kStatsWords];
         SRT_HIP(c, hipMemcpy(s, d.d_stats, sizeof(s), hipMemcpyDeviceToHost));
         SRT_HIP(c, hipMemsetAsync(d.d_stats, 0, sizeof(s), d.stream));
         SRT_HIP(c, hipStreamSynchronize(d.stream));
@@ -220,7 +221,7 @@ int collect_stats(srt_ctx* c)
         p.rays_path = s[0]; p.rays_shadow = s[1]; p.hit_nodes = s[2];
         p.box_tests = s[3]; p.sphere_tests = s[4]; p.tri_tests = s[5]; p.rect_tests = s[6];
         p.trace_sections = s[7]; p.trace_lanes = s[8]; p.light_sections = s[9]; p.light_lanes = s[10];
-        for (int i = 0; i < 16; i++) p.section_cycles[i] = s[16 + i];
+        for (int i = 0; i < 16; i++) { p.section_cycles[i] = s[16 + i]; p.section_lane_cycles[i] = s[32 + i]; }
         p.kernel_ms = ms;
         d.stats_pending = false;
         alarm = alarm || s[11] != 0ull;
@@ -232,7 +233,7 @@ int collect_stats(srt_ctx* c)
         t.rays_path += p.rays_path; t.rays_shadow += p.rays_shadow; t.hit_nodes += p.hit_nodes;
         t.box_tests += p.box_tests; t.sphere_tests += p.sphere_tests; t.tri_tests += p.tri_tests; t.rect_tests += p.rect_tests;
         t.trace_sections += p.trace_sections; t.trace_lanes += p.trace_lanes; t.light_sections += p.light_sections; t.light_lanes += p.light_lanes;
-        for (int i = 0; i < 16; i++) t.section_cycles[i] += p.section_cycles[i];
+        for (int i = 0; i < 16; i++) { t.section_cycles[i] += p.section_cycles[i]; t.section_lane_cycles[i] += p.section_lane_cycles[i]; }
         if (p.kernel_ms > t.kernel_ms) t.kernel_ms = p.kernel_ms;
     }
     if (alarm) return fail(c, SRT_E_HIP, "trace kernel: a wavefront gave up waiting for a ray subtree that another lane took over; the picture is incomplete");
@@ -483,12 +484,12 @@ int create_device(DeviceState& d, int ordinal)
     bool ok = hipSetDevice(ordinal) == hipSuccess && hipStreamCreateWithFlags(&d.stream, hipStreamNonBlocking) == hipSuccess &&
               hipEventCreate(&d.ev_begin) == hipSuccess && hipEventCreate(&d.ev_end) == hipSuccess &&
               hipEventCreateWithFlags(&d.ev_tiles, hipEventDisableTiming) == hipSuccess &&
-              hipMalloc((void**)&d.d_stats, 32 * sizeof(unsigned long long)) == hipSuccess &&
+              hipMalloc((void**)&d.d_stats, kStatsWords * sizeof(unsigned long long)) == hipSuccess &&
               hipMalloc((void**)&d.d_counter, sizeof(uint32_t)) == hipSuccess &&
 #ifdef SRT_TIMELINE
               hipMalloc((void**)&d.d_timeline, trace_timeline_bytes()) == hipSuccess &&
 #endif
-              hipMemset(d.d_stats, 0, 32 * sizeof(unsigned long long)) == hipSuccess && hipDeviceSynchronize() == hipSuccess &&
+              hipMemset(d.d_stats, 0, kStatsWords * sizeof(unsigned long long)) == hipSuccess && hipDeviceSynchronize() == hipSuccess &&
               static_scratch_setup(ordinal, &d.static_scratch) == hipSuccess;
     return ok ? SRT_OK : SRT_E_HIP;
 }
@@ -697,7 +698,7 @@ int srt_commit_scene(srt_ctx* c, int world_kind)
     c->world_kind = world_kind;
     c->committed = true;
     c->stats.build_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
-    c->stats.bvh_nodes = c->flat.n_nodes;
+    c->stats.bvh_nodes = c->flat.n_tree_nodes;
     c->stats.bvh_depth = c->flat.bvh_depth;
     c->stats.n_prims = c->flat.n_prims;
     // the host copies of the big arrays are no longer needed

@@ -216,6 +216,10 @@ struct SceneView {
     // The primitive records again, for the per-lane lookups of the winning hit (same data as `prims`; the kernels
     // point it at an LDS copy when the scene is small).
     const q4* hit_prims;
+    // Far-origin guard of the library's own tree (see trav_begin): the ball around the surfaces in the tree, the
+    // largest origin distance L0 the boxes were padded for, and the padding per unit of distance beyond it.
+    f3 far_center;
+    float far_radius, far_L0, far_slope;
 };
 
 struct Material { f3 albedo; float metalness; float smoothness; f3 emission; };
@@ -435,7 +439,7 @@ SRT_HD Hit closest_hit(const SceneView& sc, f3 o, f3 d, float t_min, Counters& c
 // A traversal is finished when tr.cur == TRAV_NONE; any split into rounds gives the result of closest_hit().
 // ------------------------------------------------------------------------------------------
 enum : uint32_t { TRAV_NONE = 0xFFFFFFFFu, TRAV_NEW = 0xFFFFFFFEu };   // both carry the leaf bit; no real leaf has 16 primitives
-struct Trav { f3 d; Hit best; uint32_t cur; int32_t sp; };
+struct Trav { f3 d; Hit best; uint32_t cur; int32_t sp; float pad; };
 
 // One child of a wide node: slab test in the node's grid.  With plane = origin + step * q the form (plane - o) * inv
 // becomes q * (step * inv) + (origin - o) * inv = q * A + B, one fused multiply-add per plane.  The caller has
@@ -444,11 +448,11 @@ struct Trav { f3 d; Hit best; uint32_t cur; int32_t sp; };
 // form by a few ulp of the distances involved, orders of magnitude below the padding of the boxes (culling is
 // conservative, not part of the arithmetic contract); NaNs (0 * inf) drop out of fmaxf / fminf, i.e. never cull.
 // Returns the entry distance, +inf for a miss.
-SRT_HD float wide_child(uint32_t nx, uint32_t ny, uint32_t nz, uint32_t fx, uint32_t fy, uint32_t fz, int shift, f3 A, f3 B, float t_best)
+SRT_HD float wide_child(uint32_t nx, uint32_t ny, uint32_t nz, uint32_t fx, uint32_t fy, uint32_t fz, int shift, f3 A, f3 Bn, f3 Bf, float t_best)
 {
-    float n1 = __builtin_fmaf((float)((nx >> shift) & 255u), A.x, B.x), f1 = __builtin_fmaf((float)((fx >> shift) & 255u), A.x, B.x);
-    float n2 = __builtin_fmaf((float)((ny >> shift) & 255u), A.y, B.y), f2 = __builtin_fmaf((float)((fy >> shift) & 255u), A.y, B.y);
-    float n3 = __builtin_fmaf((float)((nz >> shift) & 255u), A.z, B.z), f3_ = __builtin_fmaf((float)((fz >> shift) & 255u), A.z, B.z);
+    float n1 = __builtin_fmaf((float)((nx >> shift) & 255u), A.x, Bn.x), f1 = __builtin_fmaf((float)((fx >> shift) & 255u), A.x, Bf.x);
+    float n2 = __builtin_fmaf((float)((ny >> shift) & 255u), A.y, Bn.y), f2 = __builtin_fmaf((float)((fy >> shift) & 255u), A.y, Bf.y);
+    float n3 = __builtin_fmaf((float)((nz >> shift) & 255u), A.z, Bn.z), f3_ = __builtin_fmaf((float)((fz >> shift) & 255u), A.z, Bf.z);
     float tmin = max2(max2(n1, n2), n3);
     float tmax = min2(min2(f1, f2), f3_);
     bool hit = !((tmax < 0.0f) | (tmin > tmax) | (tmin > t_best));
@@ -466,6 +470,7 @@ template <bool EXACT, bool COUNT, int STRIDE>
 SRT_HD void trav_begin(const SceneView& sc, f3 o, float t_min, Trav& tr, uint32_t* stack_mem, Counters& cnt)
 {
     tr.sp = 0;
+    tr.pad = 0.0f;
     if (sc.has_bvh == 0u || (EXACT && sc.n_tiny != 0u)) {
         tr.best = closest_hit<EXACT, COUNT>(sc, o, tr.d, t_min, cnt);
         tr.cur = TRAV_NONE;
@@ -487,6 +492,15 @@ SRT_HD void trav_begin(const SceneView& sc, f3 o, float t_min, Trav& tr, uint32_
         return;
     }
     tr.best = best;
+    if (!EXACT) {
+        // The float primitive tests accept rays that miss their surface: Sphere.hit's discriminant
+        // half_b^2 - a (|oc|^2 - r^2) carries a rounding error of up to 20 * 2^-24 |oc|^2, so a ray that passes a sphere of
+        // radius r at distance m still "hits" it when m^2 <= r^2 + 20 * 2^-24 |oc|^2.  The boxes of the tree are padded
+        // for that with |oc| up to far_L0 (any origin inside the ball around the scene); a query that starts farther
+        // away widens every box it tests by far_slope times its own distance bound instead (trav_run<.., PAD>).
+        const float L = sqrt_rn(distsq3(o, sc.far_center)) + sc.far_radius;
+        tr.pad = L > sc.far_L0 ? sc.far_slope * L : 0.0f;
+    }
     if (EXACT) {
         const f3 inv = mk3(1.0f / d.x, 1.0f / d.y, 1.0f / d.z);
         q4 r0 = sc.nodes[0], r1 = sc.nodes[1];
@@ -497,7 +511,8 @@ SRT_HD void trav_begin(const SceneView& sc, f3 o, float t_min, Trav& tr, uint32_
     }
 }
 
-template <bool EXACT, bool COUNT, int STRIDE>
+// PAD: widen every box by tr.pad on all sides (queries that start far outside the scene, see trav_begin).
+template <bool EXACT, bool COUNT, int STRIDE, bool PAD = false>
 SRT_HD void trav_run(const SceneView& sc, f3 o, float t_min, Trav& tr, uint32_t* stack_mem, Counters& cnt, int rounds, int steps)
 {
     const f3 d = tr.d;
@@ -528,16 +543,23 @@ SRT_HD void trav_run(const SceneView& sc, f3 o, float t_min, Trav& tr, uint32_t*
                 if (COUNT) cnt.box_tests += nk;
                 f3 A = mk3(bitsf((meta & 255u) << 23) * inv.x, bitsf(((meta >> 8) & 255u) << 23) * inv.y, bitsf(((meta >> 16) & 255u) << 23) * inv.z);
                 f3 B = mk3((w0.x - o.x) * inv.x, (w0.y - o.y) * inv.y, (w0.z - o.z) * inv.z);
+                f3 Bn = B, Bf = B;
+                if (PAD) {
+                    // the plane the ray enters through moves towards the origin by pad, the one it leaves through away from
+                    // it: pad * |1 / d| in ray distance (an infinite 1 / d makes NaNs, which fmaxf / fminf drop: never culled)
+                    const f3 w = mk3(tr.pad * fabsf(inv.x), tr.pad * fabsf(inv.y), tr.pad * fabsf(inv.z));
+                    Bn = sub3(B, w); Bf = add3(B, w);
+                }
                 // per axis: the planes the ray enters through / leaves through (a negative direction enters at hi)
                 const bool bx = (fbits(d.x) >> 31) != 0u, by = (fbits(d.y) >> 31) != 0u, bz = (fbits(d.z) >> 31) != 0u;
                 uint32_t lx = fbits(w1.x), ly = fbits(w1.y), lz = fbits(w1.z), hx = fbits(w1.w), hy = fbits(w2.x), hz = fbits(w2.y);
                 uint32_t nx = bx ? hx : lx, fx = bx ? lx : hx, ny = by ? hy : ly, fy = by ? ly : hy, nz = bz ? hz : lz, fz = bz ? lz : hz;
                 uint32_t c0 = fbits(w2.z), c1 = fbits(w2.w), c2 = fbits(w3.x), c3 = fbits(w3.y);
                 // all four slots are evaluated (no branch on the child count); unused slots are masked afterwards
-                float t0 = wide_child(nx, ny, nz, fx, fy, fz, 0, A, B, best.t);
-                float t1 = wide_child(nx, ny, nz, fx, fy, fz, 8, A, B, best.t);
-                float t2 = wide_child(nx, ny, nz, fx, fy, fz, 16, A, B, best.t);
-                float t3 = wide_child(nx, ny, nz, fx, fy, fz, 24, A, B, best.t);
+                float t0 = wide_child(nx, ny, nz, fx, fy, fz, 0, A, Bn, Bf, best.t);
+                float t1 = wide_child(nx, ny, nz, fx, fy, fz, 8, A, Bn, Bf, best.t);
+                float t2 = wide_child(nx, ny, nz, fx, fy, fz, 16, A, Bn, Bf, best.t);
+                float t3 = wide_child(nx, ny, nz, fx, fy, fz, 24, A, Bn, Bf, best.t);
                 t1 = nk > 1u ? t1 : INFINITY; t2 = nk > 2u ? t2 : INFINITY; t3 = nk > 3u ? t3 : INFINITY;
                 sort_pair(t0, c0, t1, c1); sort_pair(t2, c2, t3, c3);
                 sort_pair(t0, c0, t2, c2); sort_pair(t1, c1, t3, c3);

@@ -91,6 +91,10 @@ __device__ __forceinline__ uint32_t next_draw(uint32_t left, uint32_t guide, uin
 }
 
 // Profiler of the counting builds: shader-clock cycles between consecutive marks, by the part that ended.
+// The records are per lane: a lane that sits out a part does not execute the marks inside it, and the time goes to the
+// next mark it does execute.  The kernels therefore mark PROF_WAIT_* where the lanes of a wavefront join again: summed
+// over the lanes, slots 0-10 hold the lane-cycles spent working in each part and the wait slots the lane-cycles spent
+// waiting for other lanes' parts.
 struct ClockProf {
     unsigned long long cyc[PROF_SLOTS] = {};
     unsigned long long t = 0ull;
@@ -298,8 +302,9 @@ __global__ void __launch_bounds__(kBlock, SMALL ? SRT_WAVES_PER_SIMD : SRT_WAVES
                 f3 ret;
                 phase = lane_return(ln, ret, sc, ra, frames);
                 if (phase == LANE_IDLE) samples[ln.slot] = ret;
+                SRT_MARK(PROF_RETURN);
             }
-            SRT_MARK(PROF_RETURN);
+            SRT_MARK(PROF_WAIT_RETURN);
             // ---- deal items to idle lanes
             unsigned long long idle = __ballot(phase == LANE_IDLE);
             while (idle != 0ull) {
@@ -326,11 +331,12 @@ __global__ void __launch_bounds__(kBlock, SMALL ? SRT_WAVES_PER_SIMD : SRT_WAVES
                 uint32_t rank = lanes_below(idle);
                 if (phase == LANE_IDLE && rank < avail) {
                     if (item_start(ln, ra, next + rank, unit)) phase = LANE_TRACE;  // padding pixels of edge tiles are skipped
+                    SRT_MARK(PROF_DEAL);
                 }
                 next += want < avail ? want : avail;
                 idle = __ballot(phase == LANE_IDLE);
             }
-            SRT_MARK(PROF_DEAL);
+            SRT_MARK(PROF_WAIT_DEAL);
             // ---- TRACE: closest-hit query of a tree node
             if (COUNT) { sect[0]++; sect[1] += (uint32_t)__popcll(__ballot(phase == LANE_TRACE)); }
             if (phase == LANE_TRACE) {
@@ -339,8 +345,9 @@ __global__ void __launch_bounds__(kBlock, SMALL ? SRT_WAVES_PER_SIMD : SRT_WAVES
                 f3 ret;
                 phase = lane_on_closest(ln, h, ret, sc, ra, frames, unit);
                 if (phase == LANE_IDLE) samples[ln.slot] = ret;
+                SRT_MARK(PROF_ON_CLOSEST);
             }
-            SRT_MARK(PROF_ON_CLOSEST);
+            SRT_MARK(PROF_WAIT_TRACE);
         } else {
             // ---- LIGHT: one shadow query per light, then the node's shading
             if (COUNT) { sect[2]++; sect[3] += (uint32_t)n_light; }
@@ -361,7 +368,7 @@ __global__ void __launch_bounds__(kBlock, SMALL ? SRT_WAVES_PER_SIMD : SRT_WAVES
                 phase = lane_shade(ln, ln.former, ret, sc, ra, frames, aux, unit, prof);
                 if (phase == LANE_IDLE) samples[ln.slot] = ret;
             }
-            SRT_MARK(PROF_CHILD_START);
+            SRT_MARK(PROF_WAIT_LIGHT);
         }
     }
 
@@ -454,6 +461,10 @@ __global__ void __launch_bounds__(kBlock, SMALL ? SRT_WAVES_PER_SIMD : SRT_WAVES
         atomicAdd(&stats[2], v2);
     }
     if constexpr (COUNT) {
+        for (int i = 0; i < PROF_SLOTS; i++) {
+            const unsigned long long lanes = wave_sum(prof.cyc[i]);
+            if (lane == 0u) atomicAdd(&stats[32 + i], lanes);
+        }
         unsigned long long c0 = wave_sum(cnt.box_tests), c1 = wave_sum(cnt.sphere_tests), c2 = wave_sum(cnt.tri_tests), c3 = wave_sum(cnt.rect_tests);
         if (lane == 0u) {
             atomicAdd(&stats[3], c0);
@@ -461,7 +472,7 @@ __global__ void __launch_bounds__(kBlock, SMALL ? SRT_WAVES_PER_SIMD : SRT_WAVES
             atomicAdd(&stats[5], c2);
             atomicAdd(&stats[6], c3);
             for (int i = 0; i < 4; i++) atomicAdd(&stats[7 + i], (unsigned long long)sect[i]);
-            for (int i = 0; i < PROF_SLOTS; i++) atomicAdd(&stats[16 + i], prof.cyc[i]);
+            for (int i = 0; i < PROF_WAIT_RETURN; i++) atomicAdd(&stats[16 + i], prof.cyc[i]);
             atomicAdd(&stats[16 + 15], (unsigned long long)handed);   // a count, not cycles
             // the tail of the launch: how long wavefronts kept running after the counter ran out (100 MHz ticks)
             const unsigned long long tail = t_exit - t_dry;
@@ -517,7 +528,7 @@ __global__ void __launch_bounds__(kBlock, SRT_WAVES_PER_SIMD_MESH) mesh_trace_ke
     Trav tr;
     tr.d = mk3(0.0f, 0.0f, 0.0f);
     tr.best.t = INFINITY; tr.best.prim = NO_PRIM; tr.best.u = tr.best.v = 0.0f; tr.best.order = 0u;
-    tr.cur = TRAV_NONE; tr.sp = 0;
+    tr.cur = TRAV_NONE; tr.sp = 0; tr.pad = 0.0f;
     uint32_t light = 0u;   // the light whose shadow query is pending
     Counters cnt;
     cnt.box_tests = cnt.sphere_tests = cnt.tri_tests = cnt.rect_tests = 0u;
@@ -604,7 +615,9 @@ __global__ void __launch_bounds__(kBlock, SRT_WAVES_PER_SIMD_MESH) mesh_trace_ke
                 const f3 o = sh ? ln.P : ln.qo;
                 const float t_min = sh ? 0.001f : ln.qtmin;
                 if (tr.cur == TRAV_NEW) trav_begin<EXACT, COUNT, 64>(sc, o, t_min, tr, my_stack, cnt);
-                trav_run<EXACT, COUNT, 64>(sc, o, t_min, tr, my_stack, cnt, rounds, steps);
+                // queries that start far outside the scene test widened boxes; a wavefront without one keeps the plain walk
+                if (!EXACT && __ballot(tr.pad != 0.0f) != 0ull) trav_run<EXACT, COUNT, 64, !EXACT>(sc, o, t_min, tr, my_stack, cnt, rounds, steps);
+                else trav_run<EXACT, COUNT, 64>(sc, o, t_min, tr, my_stack, cnt, rounds, steps);
             }
             prof.mark(PROF_CLOSEST);
         } else if (n_up >= n_closest && n_up >= n_shadow) {
@@ -687,6 +700,10 @@ __global__ void __launch_bounds__(kBlock, SRT_WAVES_PER_SIMD_MESH) mesh_trace_ke
         atomicAdd(&stats[2], v2);
     }
     if constexpr (COUNT) {
+        for (int i = 0; i < PROF_SLOTS; i++) {
+            const unsigned long long lanes = wave_sum(prof.cyc[i]);
+            if (lane == 0u) atomicAdd(&stats[32 + i], lanes);
+        }
         unsigned long long c0 = wave_sum(cnt.box_tests), c1 = wave_sum(cnt.sphere_tests), c2 = wave_sum(cnt.tri_tests), c3 = wave_sum(cnt.rect_tests);
         if (lane == 0u) {
             atomicAdd(&stats[3], c0);
@@ -694,7 +711,7 @@ __global__ void __launch_bounds__(kBlock, SRT_WAVES_PER_SIMD_MESH) mesh_trace_ke
             atomicAdd(&stats[5], c2);
             atomicAdd(&stats[6], c3);
             for (int i = 0; i < 4; i++) atomicAdd(&stats[7 + i], (unsigned long long)sect[i]);
-            for (int i = 0; i < PROF_SLOTS; i++) atomicAdd(&stats[16 + i], prof.cyc[i]);
+            for (int i = 0; i < PROF_WAIT_RETURN; i++) atomicAdd(&stats[16 + i], prof.cyc[i]);
             atomicAdd(&stats[16 + 15], (unsigned long long)handed);   // a count, not cycles
         }
     }
@@ -768,7 +785,8 @@ hipError_t launch_trace(const SceneView& sc, const RenderArgs& ra_in, bool exact
     static const uint32_t chunk_knob = std::getenv("SRT_CHUNK") ? (uint32_t)std::atoi(std::getenv("SRT_CHUNK")) : 0u;
     static const uint32_t max_blocks = std::getenv("SRT_MAX_BLOCKS") ? (uint32_t)std::atoi(std::getenv("SRT_MAX_BLOCKS")) : (uint32_t)kMaxBlocks;
     static const bool allow_small = !std::getenv("SRT_NO_LDS_SCENE");
-    const bool stackless = sc.has_bvh == 0u || (exact && sc.n_tiny != 0u);
+    static const bool force_mesh = std::getenv("SRT_FORCE_MESH_KERNEL") != nullptr;   // experiments: the quantum scheduler for every scene
+    const bool stackless = !force_mesh && (sc.has_bvh == 0u || (exact && sc.n_tiny != 0u));
     const bool small = allow_small && stackless && sc.n_prims <= kSmallPrims && sc.n_materials <= kSmallMaterials;
     // one entry per kernel instantiation: [mesh][exact][counted][small]
     static uint32_t resident[2][2][2][2] = {};

@@ -139,7 +139,8 @@ struct HybridFrames {
 // the end of each of their parts; everything else passes NoProf, whose marks compile to nothing.
 struct NoProf { SRT_HD void mark(int) const {} };
 enum { PROF_DEAL = 0, PROF_RETURN, PROF_CLOSEST, PROF_ON_CLOSEST, PROF_AUX, PROF_SHADOW_SETUP, PROF_SHADOW_QUERY, PROF_LIGHT_EVAL,
-       PROF_CHILD_DIRS, PROF_FRESNEL, PROF_CHILD_START, PROF_SLOTS = 16 };
+       PROF_CHILD_DIRS, PROF_FRESNEL, PROF_CHILD_START,
+       PROF_WAIT_RETURN = 11, PROF_WAIT_DEAL, PROF_WAIT_TRACE, PROF_WAIT_LIGHT, PROF_SLOTS = 16 };
 
 SRT_HD void lane_begin_child(Lane& ln, uint32_t child, f3 origin, f3 unit_dir, int32_t depth)
 {

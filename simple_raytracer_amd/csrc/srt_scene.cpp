@@ -783,13 +783,43 @@ int flatten_scene(const HostScene& in, int world_kind, FlatScene& out, std::stri
             }
         }
     }
+    if (world_kind == SRT_WORLD_SURFACELIST && !members.empty()) {
+        // Far-origin guard (trav_begin in srt_core.h).  Sphere.hit accepts a ray that passes a sphere of radius r at
+        // distance m when m^2 <= r^2 + kappa |oc|^2 (the rounding error of its discriminant), so the box of a sphere is
+        // widened by sqrt(r^2 + kappa L0^2) - |r| for every origin within L0 = twice the radius of the ball around the
+        // tree's surfaces (every bounce and shadow ray, every camera inside the ball); queries from farther away widen the
+        // boxes themselves, by far_slope per unit of distance: sqrt(kappa) for spheres (the bound for r -> 0), 2^-18 for
+        // the triangle test, whose error grows linearly with the distance.
+        const double kappa = 32.0 / 16777216.0;     // 32 * 2^-24: the bound is 20 * 2^-24
+        double lo[3] = {INFINITY, INFINITY, INFINITY}, hi[3] = {-INFINITY, -INFINITY, -INFINITY};
+        bool spheres_in_tree = false;
+        for (uint32_t i : members) {
+            for (int k = 0; k < 3; k++) { lo[k] = std::fmin(lo[k], (double)pb[i].mn[k]); hi[k] = std::fmax(hi[k], (double)pb[i].mx[k]); }
+            spheres_in_tree = spheres_in_tree || i >= nt;
+        }
+        double r2 = 0.0;
+        for (int k = 0; k < 3; k++) { out.far_center[k] = (float)(0.5 * (lo[k] + hi[k])); const double h = 0.5 * (hi[k] - lo[k]); r2 += h * h; }
+        const double R = std::sqrt(r2) * 1.001 + 1e-30, L0 = 2.0 * R;
+        out.far_radius = (float)R;
+        out.far_L0 = (float)(L0 * 0.999);
+        out.far_slope = spheres_in_tree ? (float)(std::sqrt(kappa) * 1.01) : 0x1p-18f;
+        if (spheres_in_tree)
+            for (uint32_t i : members) {
+                if (i < nt) continue;
+                const double r = std::fabs((double)in.sph[(size_t)(i - nt) * 4 + 3]);
+                const float e = (float)((std::sqrt(r * r + kappa * L0 * L0) - r) * 1.001);
+                for (int k = 0; k < 3; k++) { pb[i].mn[k] -= e; pb[i].mx[k] += e; }
+            }
+    }
     if (n_boxed > 0 && !tiny && (world_kind == SRT_WORLD_BVHNODE || !members.empty())) {
         if (world_kind == SRT_WORLD_BVHNODE) {
             ReferenceBuilder b(pb);
             b.run();
             for (uint32_t i = 0; i < b.leaf_order.size(); i++) emit_prim(in, b.leaf_order[i], i, prims + (size_t)i * 3);
             emit_nodes(b.nodes, out.nodes);
+            out.leaf_order = b.leaf_order;
             out.n_nodes = (uint32_t)b.nodes.size();
+            out.n_tree_nodes = out.n_nodes - 1u;
             out.bvh_depth = b.max_depth;
             if (b.nodes.size() <= (size_t)TINY_TREE_NODES) {
                 emit_tiny(b.nodes, 0, out.tiny);
@@ -809,6 +839,7 @@ int flatten_scene(const HostScene& in, int world_kind, FlatScene& out, std::stri
             out.nodes.swap(w.out);
             out.n_wide = (uint32_t)(out.nodes.size() / 4);
             out.n_nodes = out.n_wide;
+            out.n_tree_nodes = out.n_wide;
             out.bvh_depth = w.max_depth;
         }
         if (out.bvh_depth > (uint32_t)STACK_DEPTH) { err = "BVH deeper than the traversal stack"; return SRT_E_LIMIT; }

@@ -34,6 +34,13 @@ struct FlatScene {
     std::vector<q4> nodes, prims, normals, materials, lights, tiny;
     uint32_t n_lights = 0, list_first = 0, list_count = 0, has_bvh = 0, n_tiny = 0, n_wide = 0;
     uint32_t n_nodes = 0, bvh_depth = 0, n_prims = 0, n_materials = 0;
+    uint32_t n_tree_nodes = 0;   // nodes of the tree itself: BVHNode objects of the reference tree (its array has one unused slot), or wide nodes
+    // SRT_WORLD_BVHNODE: the surfaces (global index: triangles, spheres, rects) in the order the reference tree's leaves
+    // hold them, left to right -- the order BVHNode.hit visits them in.  Host-side only (tests compare it).
+    std::vector<uint32_t> leaf_order;
+    // far-origin guard of the library's own tree (SceneView::far_*); far_L0 = infinity when there is no such tree
+    float far_center[3] = {0.0f, 0.0f, 0.0f};
+    float far_radius = 0.0f, far_L0 = INFINITY, far_slope = 0.0f;
 
     // The view the kernels take, over device (or, for the CPU harness, host) copies of the arrays.
     SceneView view(const q4* d_nodes, const q4* d_prims, const q4* d_normals, const q4* d_materials, const q4* d_lights, const q4* d_tiny) const
@@ -43,6 +50,8 @@ struct FlatScene {
         v.n_lights = n_lights; v.list_first = list_first; v.list_count = list_count; v.has_bvh = has_bvh; v.n_tiny = n_tiny;
         v.n_nodes = n_nodes; v.n_prims = n_prims; v.n_materials = n_materials; v.n_wide = n_wide;
         v.hit_prims = d_prims;
+        v.far_center = mk3(far_center[0], far_center[1], far_center[2]);
+        v.far_radius = far_radius; v.far_L0 = far_L0; v.far_slope = far_slope;
         return v;
     }
 };

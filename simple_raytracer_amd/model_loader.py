@@ -2,12 +2,27 @@
 file into the world the tracer renders.
 
 The reference imports files with Assimp (AssimpContext.ImportFile with PostProcessSteps.PreTransformVertices,
-ModelLoader.cs:32), a third-party library that is not part of the reference tree.  `LoadModel` here reads the subset
-of COLLADA 1.4 that the reference's own models use -- <triangles> / <polylist> of triangles with VERTEX and NORMAL
-inputs, node <matrix> transforms, point lights, perspective cameras, the Z_UP root rotation -- and returns the same
-shape of data Assimp would (`Scene.Meshes[i].Vertices / Normals / Faces`, `Scene.Lights`, `Scene.Cameras`), with the
-node transforms already applied to the vertices ("pre-transformed").  Transforms are evaluated in double and rounded
-once; Assimp's own float rounding is not reproduced (parity with the importer is unpinned).
+ModelLoader.cs:32; any path Assimp can read), a third-party library that is not part of the reference tree.
+`LoadModel` here reads two formats and returns the same shape of data Assimp would (`Scene.Meshes[i].Vertices / Normals /
+Faces`, `Scene.Lights`, `Scene.Cameras`), with the node transforms already applied to the vertices ("pre-transformed"):
+
+* `.dae`: the subset of COLLADA 1.4 that the reference's own models use -- <triangles> / <polylist> of triangles with
+  VERTEX and NORMAL inputs, node <matrix> transforms, point lights, perspective cameras, the Z_UP root rotation.
+  Transforms are evaluated in double and rounded once; Assimp's own float rounding is not reproduced.
+* `.obj`: Wavefront `v` / `vn` / `vt` / `f` with the index forms v, v/vt, v//vn and v/vt/vn (negative indices count from
+  the end), one mesh per run of faces under one `o` / `g` / `usemtl`, one vertex per face corner.  Faces keep all their
+  corners: the reference imports without the Triangulate step and then reads the first three indices of every face
+  (ModelLoader.cs:60), so a quad contributes one triangle.  An OBJ file holds no lights, cameras or transforms.
+
+What the importer itself does -- which corners share a vertex, how meshes are split, the camera angle it derives from a
+COLLADA <perspective>, where it puts a light -- is restated from Assimp 4.1's published behaviour and is not pinned by
+anything in the reference tree (parity with the importer is unpinned):
+  - a COLLADA camera reports its HORIZONTAL field of view (aiCamera::mHorizontalFOV): <xfov> as given; with only <yfov>
+    and <aspect_ratio>, 2 atan(aspect tan(yfov / 2)); with <yfov> alone, aiCamera's default of 45 degrees.  The
+    reference then hands that angle to its Camera as the VERTICAL field of view (ModelLoader.cs:111-114);
+  - lights and cameras are not touched by PreTransformVertices' vertex baking; their position / direction are taken in
+    world space (node transforms and the up-axis rotation applied), which is what aiLight / aiCamera hold after that step
+    moved every node transform into the data.
 
 `CreateModel` and `CreateScene` then do what ModelLoader.cs:39-119 does with that data, quirks included.
 """
@@ -112,8 +127,78 @@ def _read_geometries(root):
     return geoms
 
 
+def _horizontal_fov(persp):
+    """aiCamera::mHorizontalFOV (radians) of a COLLADA <perspective>, as Assimp 4.1's loader derives it."""
+    if persp is None:
+        return np.radians(45.0)
+    x, y, a = persp.find("c:xfov", _NS), persp.find("c:yfov", _NS), persp.find("c:aspect_ratio", _NS)
+    if x is not None:
+        return np.radians(float(x.text))
+    if y is not None and a is not None:
+        return 2.0 * np.arctan(float(a.text) * np.tan(np.radians(float(y.text)) * 0.5))
+    return np.radians(45.0)
+
+
+def _load_obj(loadPath):
+    """Wavefront OBJ -> Scene: what Assimp's importer hands back without the Triangulate and JoinIdenticalVertices steps."""
+    pos, nrm = [], []
+    meshes, faces = [], []          # faces of the mesh being read: lists of (v, vn) index pairs
+
+    def close():
+        if not faces:
+            return
+        verts, normals, idx = [], [], []
+        for f in faces:
+            corners = []
+            for v, n in f:
+                if n is None:
+                    raise ValueError("%s: a face without normals (the reference indexes mesh.Normals, which is then empty)" % loadPath)
+                corners.append(len(verts))
+                verts.append(pos[v])
+                normals.append(nrm[n])
+            idx.append(corners[:3])     # ModelLoader.cs:60 reads indices[0..2] only
+        meshes.append(Mesh(verts, normals, idx))
+        faces.clear()
+
+    def resolve(token, count):
+        i = int(token)
+        i = i - 1 if i > 0 else count + i
+        if not 0 <= i < count:
+            raise ValueError("%s: index %s out of range" % (loadPath, token))
+        return i
+
+    with open(loadPath, "r", encoding="utf-8", errors="replace") as fh:
+        for raw in fh:
+            line = raw.split("#", 1)[0].split()
+            if not line:
+                continue
+            key = line[0]
+            if key == "v":
+                pos.append([float(x) for x in line[1:4]])
+            elif key == "vn":
+                nrm.append([float(x) for x in line[1:4]])
+            elif key in ("o", "g", "usemtl"):
+                close()
+            elif key == "f":
+                if len(line) - 1 < 3:
+                    raise ValueError("%s: a face with fewer than three corners (the reference indexes three)" % loadPath)
+                corners = []
+                for tok in line[1:]:
+                    parts = tok.split("/")
+                    v = resolve(parts[0], len(pos))
+                    n = resolve(parts[2], len(nrm)) if len(parts) > 2 and parts[2] else None
+                    corners.append((v, n))
+                faces.append(corners)
+    close()
+    return Scene(meshes)
+
+
 def LoadModel(loadPath):
     """ModelLoader.cs:16-37.  Returns a Scene with pre-transformed meshes, lights and cameras."""
+    if str(loadPath).lower().endswith(".obj"):
+        return _load_obj(loadPath)
+    if not str(loadPath).lower().endswith(".dae"):
+        raise ValueError("%s: only COLLADA (.dae) and Wavefront (.obj) files are read" % loadPath)
     root = ET.parse(loadPath).getroot()
     up = root.find("c:asset/c:up_axis", _NS)
     up = up.text.strip() if up is not None and up.text else "Y_UP"
@@ -126,11 +211,7 @@ def LoadModel(loadPath):
     cams_lib = {}
     for c in root.findall("c:library_cameras/c:camera", _NS):
         persp = c.find("c:optics/c:technique_common/c:perspective", _NS)
-        fov = 45.0
-        if persp is not None:
-            x, y = persp.find("c:xfov", _NS), persp.find("c:yfov", _NS)
-            fov = float((x if x is not None else y).text) if (x is not None or y is not None) else fov
-        cams_lib["#" + c.get("id")] = np.radians(fov)
+        cams_lib["#" + c.get("id")] = _horizontal_fov(persp)
 
     scene = Scene()
 

@@ -190,6 +190,7 @@ class Renderer:
     def _stats_dict(st):
         out = {k: getattr(st, k) for k, _ in N.Stats._fields_ if k != "reserved"}
         out["section_cycles"] = list(st.section_cycles)
+        out["section_lane_cycles"] = list(st.section_lane_cycles)
         return out
 
     def stats(self):

@@ -44,7 +44,8 @@ Hit query(const SceneView& sc, f3 o, f3 d, float t_min, uint32_t* stack, Counter
     trav_begin<EXACT, true, 1>(sc, o, t_min, tr, stack, cnt);
     int budget = 1;
     while (tr.cur != TRAV_NONE) {
-        trav_run<EXACT, true, 1>(sc, o, t_min, tr, stack, cnt, 1, budget);
+        if (!EXACT && tr.pad != 0.0f) trav_run<EXACT, true, 1, !EXACT>(sc, o, t_min, tr, stack, cnt, 1, budget);
+        else trav_run<EXACT, true, 1>(sc, o, t_min, tr, stack, cnt, 1, budget);
         budget = budget % 3 + 1;
     }
     return tr.best;
@@ -177,7 +178,7 @@ int srt_commit_scene(srt_ctx* c, int world_kind)
     if (rc != SRT_OK) return rc;
     c->world_kind = world_kind;
     c->committed = true;
-    c->stats.bvh_nodes = c->flat.n_nodes; c->stats.bvh_depth = c->flat.bvh_depth; c->stats.n_prims = c->flat.n_prims;
+    c->stats.bvh_nodes = c->flat.n_tree_nodes; c->stats.bvh_depth = c->flat.bvh_depth; c->stats.n_prims = c->flat.n_prims;
     return SRT_OK;
 }
 
@@ -339,6 +340,13 @@ int64_t srt_emu_item_order(srt_ctx* c, const srt_render_params* p, uint32_t scat
         pixels[item] = real ? ln.key.pixel : 0xFFFFFFFFu;
     }
     return (int64_t)ra.n_items;
+}
+// Test hook: the surfaces of a committed SRT_WORLD_BVHNODE world in the order the tree's leaves hold them.
+int64_t srt_emu_leaf_order(srt_ctx* c, uint32_t* out, uint64_t capacity)
+{
+    if (!c->committed || c->flat.leaf_order.size() > capacity) return -1;
+    for (size_t i = 0; i < c->flat.leaf_order.size(); i++) out[i] = c->flat.leaf_order[i];
+    return (int64_t)c->flat.leaf_order.size();
 }
 // FNV-1a over the flattened arrays of the committed scene (nodes, primitives, normals): two builds of one scene
 // give the same digest exactly when they laid out the same tree.

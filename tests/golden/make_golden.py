@@ -30,6 +30,8 @@ GOLDEN = {
     "teapot_dae_normal_list_64x36": ("teapot_spec", {}, 64, 36, 1, 4, orc.MODE_NORMAL, orc.WORLD_SURFACELIST, 1),
     "teapot_dae_color_1spp_list_64x36": ("teapot_spec", {}, 64, 36, 1, 4, orc.MODE_COLOR, orc.WORLD_SURFACELIST, 1),
     "teapot_dae_color_4spp_bvhnode_64x36": ("teapot_spec", {}, 64, 36, 4, 4, orc.MODE_COLOR, orc.WORLD_BVHNODE, 1),
+    "tiny_obj_color_4spp_bvhnode_64x36": ("obj_spec", {}, 64, 36, 4, 4, orc.MODE_COLOR, orc.WORLD_BVHNODE, 1),
+    "tiny_obj_normal_list_64x36": ("obj_spec", {}, 64, 36, 1, 4, orc.MODE_NORMAL, orc.WORLD_SURFACELIST, 1),
 }
 
 

@@ -212,6 +212,25 @@ def stray_spec(kind):
     return s
 
 
+def far_camera_spec(distance, with_mesh=False):
+    """Thirteen spheres (radius 0.02 .. 1) around the origin, optionally with a triangle-mesh sphere among them, seen
+    through a narrow lens from `distance` away.  Far from the scene the float surface tests lose their low bits:
+    Sphere.hit's discriminant half_b^2 - a (|oc|^2 - r^2) cancels catastrophically, and at a distance of 10,000 a ray
+    that passes a unit sphere 1.5 units away still "hits" it.  The reference's list scan reports those hits, so a tree
+    that answers SurfaceList.hit must not cull them."""
+    s = SceneSpec()
+    s.materials = [((0.8, 0.5, 0.5), 0.0, 0.5, (0, 0, 0)), ((0.6, 0.7, 0.9), 0.5, 0.8, (0, 0, 0))]
+    rng = np.random.default_rng(3)
+    s.spheres = [((0.0, 0.0, 0.0), 1.0, 0)] + [((float(x), float(y), float(z)), float(r), 1)
+                                               for (x, y, z), r in zip(rng.uniform(-4, 4, (12, 3)), rng.uniform(0.02, 0.6, 12))]
+    if with_mesh:
+        p, n = uv_sphere((0.5, 1.0, 0.5), 1.5, 8, 16)
+        s.meshes.append((p, n, 1, False, True))
+    s.lights = [((0.0, -30.0, 0.0), 5.0, None)]
+    s.camera = ((distance, 0, 0), (0, 0, 0), float(np.degrees(2 * np.arctan(6.0 / distance))))
+    return s
+
+
 def nasty_spec(seed):
     """Random small scenes made of the inputs a model file can hold and a tree builder trips over: zero-length
     edges, collinear and duplicated triangles, vertices on a lattice (equal hit distances), coplanar triangles,
@@ -258,6 +277,22 @@ def teapot_spec():
     s = SceneSpec()
     s.materials = [((1.0, 0.5, 0.5), 0.0, 0.85, (0, 0, 0))]
     s.meshes.append((d["pos9"], d["nrm9"], 0, False, True))
+    s.lights = [((6.0, 2.0, 3.0), 5.0, None), ((0.0, 0.0, -12.0), 2.5, None)]
+    s.camera = ((0, 0, 6), (0, 0, 0), 29)
+    return s
+
+
+def obj_spec():
+    """tests/golden/tiny_scene.obj through the ModelLoader mirror (LoadModel + CreateScene, ModelLoader.cs:16-119): a
+    pyramid and one triangle of a floor quad, material mat6 (Game1.cs:109), the loader's fallback camera (an OBJ file has
+    none) and the two Game1 lights (it has no lights either)."""
+    from simple_raytracer_amd import model_loader
+    model = model_loader.LoadModel(os.path.join(GOLDEN, "tiny_scene.obj"))
+    s = SceneSpec()
+    s.materials = [((1.0, 0.5, 0.5), 0.0, 0.85, (0, 0, 0))]
+    for mesh in model.Meshes:
+        pos9, nrm9 = model_loader._mesh_arrays(mesh, (0.0, 0.0, 0.0))
+        s.meshes.append((pos9, nrm9, 0, False, True))
     s.lights = [((6.0, 2.0, 3.0), 5.0, None), ((0.0, 0.0, -12.0), 2.5, None)]
     s.camera = ((0, 0, 6), (0, 0, 0), 29)
     return s

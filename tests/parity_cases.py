@@ -59,6 +59,12 @@ CASES = [
     ("stray-1e20-bvhnode", lambda: helpers.stray_spec("1e20"), 48, 27, 1, 3, COLOR, BVH, 2),
     ("stray-nan-bvhnode", lambda: helpers.stray_spec("nan"), 48, 27, 1, 3, COLOR, BVH, 2),
 ]
+# cameras far from the scene: the float surface tests accept rays that miss their surface by a wide margin there
+# (helpers.far_camera_spec); the library's tree has to return those hits like the list scan does
+for _d in (1e3, 1e4, 1e6):
+    CASES.append(("far-camera-%g-list" % _d, (lambda d=_d: helpers.far_camera_spec(d)), 64, 36, 2, 3, COLOR, LIST, 1))
+CASES.append(("far-camera-1e4-mesh-list", lambda: helpers.far_camera_spec(1e4, True), 64, 36, 1, 3, COLOR, LIST, 2))
+CASES.append(("far-camera-1e4-bvhnode", lambda: helpers.far_camera_spec(1e4), 64, 36, 1, 3, COLOR, BVH, 1))
 # degenerate surfaces (see helpers.nasty_spec); seeds 36, 44, 50, 56, 68, 77 hold spheres of negative radius
 for _seed in (3, 36, 44, 50, 56, 68, 77, 101, 102, 103):
     _spec = helpers.nasty_spec(_seed)

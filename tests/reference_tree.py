@@ -1,0 +1,44 @@
+"""The reference's own BVH (new BVHNode(world), RaytracingClasses.cs:346-426) as the library builds and walks it for
+SRT_WORLD_BVHNODE worlds, pinned against the oracle's pointer tree: node count, depth, the order of the surfaces in the
+leaves, and the number of box / sphere / triangle tests of a render.
+
+The oracle counts every test the reference performs; the library reuses two answers the reference computes again (the
+per-light re-intersection of the node's own ray, RaytracingClasses.cs:211, and the second test of a single-surface leaf,
+:362-365), and the oracle counts those repeats separately, so tests - repeats must be the library's counts exactly.  A
+tree of another shape that happened to give the same picture would fail here."""
+import numpy as np
+
+import helpers
+import simple_raytracer_amd as srt
+
+SCENES = {
+    "game1": (lambda: helpers.default_spec(), 96, 54, 2, 8),
+    "glossy": (lambda: helpers.glossy_spec(), 64, 36, 1, 8),
+    "mesh+spheres": (lambda: helpers.mesh_spec(), 64, 36, 1, 4),
+    "mesh-only": (lambda: helpers.mesh_spec(with_spheres=False), 48, 27, 1, 3),
+    "teapot.dae": (lambda: helpers.teapot_spec(), 48, 27, 1, 2),
+}
+
+
+def run(renderer, orc, name):
+    """-> (library stats, oracle stats, library (nodes, depth), oracle (nodes, depth), max LSB)."""
+    make, w, h, spp, depth = SCENES[name]
+    spec = make()
+    world, lights, cam = spec.host(w, h)
+    renderer.set_scene(world, lights, cam, world_kind=srt.WORLD_BVHNODE)
+    img = renderer.render(w, h, samples=spp, max_depth=depth, seed=5, counted=True)
+    st = renderer.stats()
+    osc = spec.oracle_scene()
+    ref, ost = osc.render(spec.oracle_camera(w, h), w, h, samples=spp, max_depth=depth, seed=5, world_kind=orc.WORLD_BVHNODE)
+    lsb, _ = helpers.max_lsb_diff(img, ref)
+    return st, ost, (st["bvh_nodes"], st["bvh_depth"]), (osc.bvh_nodes(), osc.bvh_depth()), lsb, osc
+
+
+def check_counts(st, ost):
+    for k in ("rays_path", "rays_shadow", "hit_nodes"):
+        assert st[k] == ost[k], k
+    assert ost["rays_redundant"] == ost["rays_shadow"]              # one re-intersection per light of every hit node
+    for kind in ("box", "sphere", "tri"):
+        assert st[kind + "_tests"] == ost[kind + "_tests"] - ost[kind + "_repeats"], (
+            kind, st[kind + "_tests"], ost[kind + "_tests"], ost[kind + "_repeats"])
+    assert st["box_tests"] > 0

@@ -369,3 +369,16 @@ def test_gpu_sphere_cloud_with_mesh_matches_linear_scan(gpu, oracle):
     lsb, npx, colours, nodes, st, ost = mesh_cases.sphere_cloud_window(gpu, oracle)
     assert lsb <= 1 and colours > 20 and nodes > 100000, (lsb, npx, colours, nodes)
     assert st["n_prims"] == 993040
+
+
+import reference_tree  # noqa: E402
+
+
+@pytest.mark.parametrize("name", sorted(reference_tree.SCENES))
+def test_gpu_reference_tree_counts_are_the_oracles(gpu, oracle, name):
+    """The BVHNode world on the GPU: the tree has the oracle's node count and depth, and the counting kernels perform
+    exactly the box / sphere / triangle tests the reference performs, minus the repeats the library reuses."""
+    st, ost, mine, theirs, lsb, _ = reference_tree.run(gpu, oracle, name)
+    assert lsb <= 1
+    assert mine == theirs, (mine, theirs)
+    reference_tree.check_counts(st, ost)

@@ -171,3 +171,23 @@ def test_a_rank_of_several_cannot_render_a_row_major_frame(emu):
     import ctypes as C
     p = emu.params(64, 36, layout=srt.LAYOUT_FRAME, rank=0, world_size=2)
     assert emu._lib.srt_local_pixels(C.byref(p)) == srt._native.E_INVALID
+
+
+import reference_tree  # noqa: E402
+
+
+@pytest.mark.parametrize("name", sorted(reference_tree.SCENES))
+def test_reference_tree_is_the_oracles_tree(emu, oracle, name):
+    """Shape (nodes, depth, leaf order) and test counts of the BVHNode world against the oracle's pointer tree."""
+    import ctypes as C
+    import numpy as np
+    st, ost, mine, theirs, lsb, osc = reference_tree.run(emu, oracle, name)
+    assert lsb == 0
+    assert mine == theirs, (mine, theirs)
+    reference_tree.check_counts(st, ost)
+    fn = emu._lib.srt_emu_leaf_order
+    fn.restype = C.c_int64
+    order = np.empty(st["n_prims"], np.uint32)
+    n = fn(emu._ctx, order.ctypes.data_as(C.c_void_p), C.c_uint64(len(order)))
+    assert n == st["n_prims"]
+    assert list(order) == list(osc.bvh_leaf_order())

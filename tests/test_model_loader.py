@@ -28,6 +28,56 @@ def test_load_model_applies_node_transforms_and_up_axis():
     assert abs(sc.Cameras[0].FieldOfview - np.radians(40)) < 1e-6
 
 
+TINY_OBJ = os.path.join(helpers.GOLDEN, "tiny_scene.obj")
+
+
+def test_load_model_reads_wavefront_obj():
+    sc = model_loader.LoadModel(TINY_OBJ)
+    assert len(sc.Lights) == 0 and len(sc.Cameras) == 0
+    # a mesh per run of faces under one o / g / usemtl, a vertex per face corner
+    assert [m.Faces.tolist() for m in sc.Meshes] == [[[0, 1, 2], [3, 4, 5]], [[0, 1, 2], [3, 4, 5]], [[0, 1, 2]]]
+    front, back, floor = sc.Meshes
+    assert np.array_equal(front.Vertices[[0, 1, 2]], np.float32([[-1.0, -0.6, -5.0], [1.0, -0.6, -5.0], [0.0, 1.2, -6.0]]))       # f 1//1 2//1 5//5
+    assert np.allclose(front.Normals[[0, 2]], [[0.0, 0.5145, 0.8575], [0.0, 2.0, 0.0]])
+    assert np.array_equal(front.Vertices[3], np.float32([1.0, -0.6, -5.0])) and np.allclose(front.Normals[3], [0.8575, 0.5145, 0.0])   # v/vt/vn
+    # negative indices count back from the end of what has been read so far: -5 is vertex 1, -1 vertex 5
+    assert np.array_equal(back.Vertices[[3, 4, 5]], np.float32([[-1.0, -0.6, -5.0], [1.0, -0.6, -5.0], [0.0, 1.2, -6.0]]))
+    # the quad keeps its four corners, but only the first three indices of a face are read (ModelLoader.cs:60)
+    assert floor.Vertices.shape == (4, 3) and floor.Faces.tolist() == [[0, 1, 2]]
+    world, lights = SurfaceList(), LightList()
+    cam = model_loader.CreateScene(sc, game1.materials()[5], world, lights, 16 / 9)
+    flat = world.flatten()
+    assert flat["tri_pos"].shape == (5, 9) and flat["tri_flags"].tolist() == [2] * 5
+    assert np.allclose(np.linalg.norm(flat["tri_nrm"].reshape(-1, 3), axis=1), 1.0, atol=1e-6)          # Vector3.Normalize
+    ref = model_loader.Camera((0, 0, 6), (0, 0, 0), 29, 16 / 9)                                         # no camera in the file
+    assert np.allclose(cam.lowerLeftCorner, ref.lowerLeftCorner)
+
+
+def test_load_model_refuses_what_the_reference_would_trip_over(tmp_path):
+    p = tmp_path / "no_normals.obj"
+    p.write_text("v 0 0 0\nv 1 0 0\nv 0 1 0\nf 1 2 3\n")
+    with pytest.raises(ValueError):
+        model_loader.LoadModel(str(p))           # mesh.Normals is empty: normalList[i] throws in the reference
+    p = tmp_path / "line.obj"
+    p.write_text("v 0 0 0\nv 1 0 0\nvn 0 0 1\nf 1//1 2//1\n")
+    with pytest.raises(ValueError):
+        model_loader.LoadModel(str(p))           # indices[2] does not exist
+    with pytest.raises(ValueError):
+        model_loader.LoadModel(str(tmp_path / "model.fbx"))
+
+
+def test_collada_camera_reports_the_horizontal_field_of_view(tmp_path):
+    """Assimp derives aiCamera::mHorizontalFOV: xfov as given, else from yfov and the aspect ratio, else 45 degrees."""
+    text = open(TINY).read()
+    assert abs(model_loader.LoadModel(TINY).Cameras[0].FieldOfview - np.radians(40)) < 1e-6
+    p = tmp_path / "yfov.dae"
+    p.write_text(text.replace('<xfov sid="xfov">40</xfov>', '<yfov sid="yfov">40</yfov>'))
+    want = 2 * np.arctan(1.5 * np.tan(np.radians(40) / 2))
+    assert abs(model_loader.LoadModel(str(p)).Cameras[0].FieldOfview - want) < 1e-6
+    p.write_text(text.replace('<xfov sid="xfov">40</xfov>', '<yfov sid="yfov">40</yfov>').replace("<aspect_ratio>1.5</aspect_ratio>", ""))
+    assert abs(model_loader.LoadModel(str(p)).Cameras[0].FieldOfview - np.radians(45)) < 1e-6
+
+
 def test_create_scene_quirks():
     sc = model_loader.LoadModel(TINY)
     mat6 = game1.materials()[5]

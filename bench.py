@@ -296,7 +296,8 @@ def main():
                        "name": args.config, "width": width, "height": height, "spp": spp, "max_depth": depth, "seed": 1,
                        "devices": info["devices"] if in_library else [device_index], "rccl_ranks": info["rccl_ranks"] if in_library else (world if world > 1 and backend == "nccl" else 0),
                        "path_rays_per_step": total_rays / args.steps, "shadow_rays_per_step": total_shadow / args.steps,
-                       "scene_commit_s": round(commit_s, 3), "bvh_nodes": cst["bvh_nodes"], "surfaces": cst["n_prims"]},
+                       "scene_commit_s": round(commit_s, 3), "bvh_nodes": cst["bvh_nodes"], "surfaces": cst["n_prims"],
+                       "walk_tune": cst["walk_tune"]},
             "rays_per_step": total_rays / args.steps, "shadow_rays_per_step": total_shadow / args.steps,
             "traversals_per_sec_M": round((total_rays + total_shadow) / elapsed / 1e6, 2),
             "roofline": roofline,

@@ -146,7 +146,8 @@ typedef struct {
     uint32_t bvh_nodes;      /* nodes of the committed tree: BVHNode objects of the reference tree (32 bytes each) or the library's 4-wide nodes (64) */
     uint32_t bvh_depth;
     uint32_t n_prims;
-    uint32_t reserved;
+    uint32_t walk_tune;      /* scenes whose tree is walked with a stack: traversal quantum in use, 0 long, 1 short, 2 not measured yet
+                                (the first launches after a commit measure both and keep the faster) */
     /* Wavefront occupancy of the trace kernel (only filled by srt_render_counted): how often a wavefront ran its
        closest-hit section / its light section, and how many of the 64 lanes took part, summed. */
     uint64_t trace_sections, trace_lanes, light_sections, light_lanes;

@@ -55,7 +55,7 @@ class Stats(C.Structure):
     _fields_ = [("rays_path", C.c_uint64), ("rays_shadow", C.c_uint64), ("hit_nodes", C.c_uint64), ("box_tests", C.c_uint64),
                 ("sphere_tests", C.c_uint64), ("tri_tests", C.c_uint64), ("rect_tests", C.c_uint64),
                 ("kernel_ms", C.c_double), ("build_ms", C.c_double),
-                ("bvh_nodes", C.c_uint32), ("bvh_depth", C.c_uint32), ("n_prims", C.c_uint32), ("reserved", C.c_uint32),
+                ("bvh_nodes", C.c_uint32), ("bvh_depth", C.c_uint32), ("n_prims", C.c_uint32), ("walk_tune", C.c_uint32),
                 ("trace_sections", C.c_uint64), ("trace_lanes", C.c_uint64), ("light_sections", C.c_uint64), ("light_lanes", C.c_uint64),
                 ("section_cycles", C.c_uint64 * 16), ("section_lane_cycles", C.c_uint64 * 16)]
 

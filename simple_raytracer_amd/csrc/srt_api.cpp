@@ -88,6 +88,9 @@ struct DeviceState {
     bool launched = false;
     srt_stats part{};                     // this device's share of the last collection
     unsigned char* static_scratch = nullptr;   // this GPU's copy of the library's static workspace (srt_render_device_static)
+    // Traversal quantum of the mesh kernel for the committed scene: measured by the first launches after a commit
+    // (WALK_TUNE_CALIBRATE), then fixed to what they found.
+    int walk_tune = WALK_TUNE_CALIBRATE;
 };
 
 }  // namespace
@@ -222,6 +225,8 @@ int collect_stats(srt_ctx* c)
         p.box_tests = s[3]; p.sphere_tests = s[4]; p.tri_tests = s[5]; p.rect_tests = s[6];
         p.trace_sections = s[7]; p.trace_lanes = s[8]; p.light_sections = s[9]; p.light_lanes = s[10];
         for (int i = 0; i < 16; i++) { p.section_cycles[i] = s[16 + i]; p.section_lane_cycles[i] = s[32 + i]; }
+        if (d.walk_tune == WALK_TUNE_CALIBRATE && s[13] >= kWalkTuneEnoughTicks && s[15] >= kWalkTuneEnoughTicks)
+            d.walk_tune = walk_tune_prefers_short((double)s[12], (double)s[13], (double)s[14], (double)s[15]) ? WALK_TUNE_SHORT : WALK_TUNE_LONG;
         p.kernel_ms = ms;
         d.stats_pending = false;
         alarm = alarm || s[11] != 0ull;
@@ -236,6 +241,7 @@ int collect_stats(srt_ctx* c)
         for (int i = 0; i < 16; i++) { t.section_cycles[i] += p.section_cycles[i]; t.section_lane_cycles[i] += p.section_lane_cycles[i]; }
         if (p.kernel_ms > t.kernel_ms) t.kernel_ms = p.kernel_ms;
     }
+    c->stats.walk_tune = (uint32_t)c->dev[0].walk_tune;
     if (alarm) return fail(c, SRT_E_HIP, "trace kernel: a wavefront gave up waiting for a ray subtree that another lane took over; the picture is incomplete");
     return SRT_OK;
 }
@@ -342,7 +348,7 @@ int launch(srt_ctx* c, DeviceState& d, const srt_render_params* p, uint32_t* d_o
             ra.sample_first = (uint32_t)b;
             ra.sample_count = 1u;
             ra.n_items = ra.n_work;
-            hipError_t e = launch_trace(view, ra, exact, counted, ws.samples, d.d_stats, ws.counter, d.d_timeline, stream);
+            hipError_t e = launch_trace(view, ra, exact, counted, ws.samples, d.d_stats, ws.counter, d.d_timeline, stream, d.walk_tune);
             if (e != hipSuccess) return hip_fail(c, e, "trace kernel launch");
             e = launch_resolve(ra, ws.samples, ws.running, c->d_mix, true, true, 0.0f, stream);
             if (e != hipSuccess) return hip_fail(c, e, "resolve kernel launch");
@@ -358,7 +364,7 @@ int launch(srt_ctx* c, DeviceState& d, const srt_render_params* p, uint32_t* d_o
         ra.sample_first = s0;
         ra.sample_count = (uint32_t)ra.samples - s0 < (uint32_t)per_pass ? (uint32_t)ra.samples - s0 : (uint32_t)per_pass;
         ra.n_items = ra.n_work * ra.sample_count;
-        hipError_t e = launch_trace(view, ra, exact, counted, ws.samples, d.d_stats, ws.counter, d.d_timeline, stream);
+        hipError_t e = launch_trace(view, ra, exact, counted, ws.samples, d.d_stats, ws.counter, d.d_timeline, stream, d.walk_tune);
         if (e != hipSuccess) return hip_fail(c, e, "trace kernel launch");
         const uint32_t done = s0 + ra.sample_count;
         const float preview = progressive ? (float)ra.samples / (float)done : 0.0f;
@@ -688,6 +694,7 @@ int srt_commit_scene(srt_ctx* c, int world_kind)
         SRT_HIP(c, hipSetDevice(d.device));
         SRT_HIP(c, hipStreamSynchronize(d.stream));
         free_scene_buffers(d);
+        d.walk_tune = WALK_TUNE_CALIBRATE;
         if ((rc = upload(c, c->flat.nodes, &d.d_nodes)) != SRT_OK) return rc;
         if ((rc = upload(c, c->flat.prims, &d.d_prims)) != SRT_OK) return rc;
         if ((rc = upload(c, c->flat.normals, &d.d_normals)) != SRT_OK) return rc;

@@ -128,7 +128,9 @@ struct TreeFork {
 };
 constexpr uint32_t kMaxStalledTrips = 4096u;   // trips in a row with only waiting lanes before a wavefront gives up (never reached unless a colour is lost)
 constexpr int kStatsAlarm = 11;                // stats word that counts wavefronts that gave up
+constexpr int kStatsTune = 12;                 // stats words 12-15: traversals finished / wall-clock ticks under quantum preset 0, then 1
 constexpr int kForkMinDepth = 2;       // only subtrees that can still grow (remaining depth >= this)
+constexpr int kSteadyForkDepth = 5;    // mesh kernel, while new items are left: only subtrees with at least this much depth left
 constexpr size_t kTimelinePerWave = 64;     // -DSRT_TIMELINE builds: float4 entries of scratch per wavefront of the grid
 
 enum { LANE_DELIVER = 5 };
@@ -503,11 +505,24 @@ __global__ void __launch_bounds__(kBlock, SMALL ? SRT_WAVES_PER_SIMD : SRT_WAVES
 enum { MESH_IDLE = 0, MESH_CLOSEST = 1, MESH_SHADOW = 2, MESH_RETURN = 3, MESH_WAIT = 4 };
 static_assert(MESH_IDLE == LANE_IDLE && MESH_RETURN == LANE_RETURN && MESH_WAIT == LANE_WAIT, "the subtree-sharing helpers take either kernel's phases");
 constexpr int kWalkVote = 16, kWalkRounds = 1 << 24, kWalkSteps = 2;
+// The other setting: short quanta.  Where the traversals of a wavefront differ a lot in length (rays scattered by a cloud
+// of spheres: the 10,000-sphere scene takes 706 ms per 1080p 16-spp frame with the quanta above and 531 ms with these),
+// lanes that are done move on instead of waiting for the longest walk; where they are alike (a single mesh), splitting
+// them only adds trips (983,040 triangles: 30.8 -> 42.9 ms).  Which one a scene wants is measured, not guessed: the first
+// launches after a commit run both for 3 ms each (preset 0, then preset 1, once the launch is 5 ms old), every wavefront adds the traversals
+// it finished and the time it took to two pairs of counters, and whoever finds both pairs filled takes the faster preset;
+// the host reads the same counters when it collects the statistics and fixes the preset for later launches.
+constexpr int kShortVote = 56, kShortRounds = 4, kShortSteps = 4;
+constexpr uint32_t kShortScatterSamples = 0xFFFFFFFFu;   // a short-quanta scene enumerates all samples of a pass in scattered order (8 of 16: 481 ms, all: 457 ms)
+constexpr unsigned long long kTuneWindowTicks = 300000ull;   // 3 ms of the 100 MHz wall clock per preset ...
+constexpr unsigned long long kTuneSkipTicks = 500000ull;     // ... after the first 5 ms of the launch: it starts with nothing but coherent primary rays
+struct WalkTune { int vote[2], rounds[2], steps[2]; int mode; };   // mode: WALK_TUNE_*; preset 0 / 1
 
 template <bool EXACT, bool COUNT>
 __global__ void __launch_bounds__(kBlock, SRT_WAVES_PER_SIMD_MESH) mesh_trace_kernel(SceneView sc, RenderArgs ra, f3* __restrict__ samples,
                                                             unsigned long long* __restrict__ stats, uint32_t* __restrict__ work_counter,
-                                                            float4* __restrict__ timeline /* -DSRT_TIMELINE builds only */, int walk_vote, int rounds, int steps, uint32_t chunk, uint32_t guide, int share)
+                                                            float4* __restrict__ timeline /* -DSRT_TIMELINE builds only */, WalkTune tune, uint32_t chunk, uint32_t guide, int share,
+                                                            int steady_depth)
 {
     __shared__ uint32_t lds_stack[kWaves * STACK_DEPTH * 64];
     __shared__ uint32_t lds_pair[kWaves * 64];   // handing over subtrees: giver lane by rank
@@ -548,16 +563,37 @@ __global__ void __launch_bounds__(kBlock, SRT_WAVES_PER_SIMD_MESH) mesh_trace_ke
     typename std::conditional<COUNT, ClockProf, NoProf>::type prof;
     uint32_t next = 0u, end = 0u, draw = chunk;
     bool dry = false;
+    // wave-uniform: the quantum preset in use, and the state of its calibration (see WalkTune)
+    int preset = tune.mode == WALK_TUNE_SHORT ? 1 : 0;
+    bool calibrating = tune.mode == WALK_TUNE_CALIBRATE;
+    int tune_window = 0;
+    uint32_t tune_done = 0u;
+    unsigned long long tune_start = 0ull;
+    // takes the faster preset once both have been measured enough (`force`: with whatever there is)
+    auto settle = [&](bool force) {
+        const unsigned long long q0 = __hip_atomic_load(&stats[kStatsTune + 0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const unsigned long long t0 = __hip_atomic_load(&stats[kStatsTune + 1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const unsigned long long q1 = __hip_atomic_load(&stats[kStatsTune + 2], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const unsigned long long t1 = __hip_atomic_load(&stats[kStatsTune + 3], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const bool enough = t0 >= kWalkTuneEnoughTicks && t1 >= kWalkTuneEnoughTicks;
+        if (!enough && !force) return;
+        preset = enough && walk_tune_prefers_short((double)q0, (double)t0, (double)q1, (double)t1) ? 1 : 0;
+        preset = __builtin_amdgcn_readfirstlane(preset);
+        calibrating = false;
+    };
+    if (calibrating) { settle(false); tune_start = wall_clock64(); }
 
     // the lane's next state after a per-lane function returned LANE_*; `ret` is the sample's colour for LANE_IDLE;
     // up: the function was lane_return (frames may have gone, a later child may have started), else a frame may have
     // been pushed
     auto enter = [&](int lane_phase, f3 ret, bool up) {
-        if (sharing) {
+        // While there are new items, only subtrees that can still grow large (steady_depth levels left) may change lanes:
+        // they are what keeps a single lane busy long after the rest of its wavefront has moved on.
+        if (share != 0) {
             if (up) {
                 open &= ln.level < 16 ? (1u << (2 * ln.level)) - 1u : 0xFFFFFFFFu;
                 if (lane_phase == LANE_TRACE && ln.level - 1 < kForkLevels) open &= ~(1u << (2 * (ln.level - 1) + (int32_t)((ln.key.node & 3u) - 1u) - 1));
-            } else if (lane_phase == LANE_TRACE && ln.level >= 1 && ln.level - 1 < kForkLevels && ln.depth >= kForkMinDepth) {
+            } else if (lane_phase == LANE_TRACE && ln.level >= 1 && ln.level - 1 < kForkLevels && ln.depth >= (sharing ? kForkMinDepth : steady_depth)) {
                 const float metal = sc.materials[2u * ln.mat].w;
                 if (metal != 0.0f) open |= 1u << (2 * (ln.level - 1));
                 if (metal != 1.0f) open |= 2u << (2 * (ln.level - 1));
@@ -582,12 +618,32 @@ __global__ void __launch_bounds__(kBlock, SRT_WAVES_PER_SIMD_MESH) mesh_trace_ke
 
     for (;;) {
         if constexpr (COUNT) prof.start();
+        if (calibrating) {
+            const unsigned long long now = wall_clock64();
+            if (dry) settle(true);      // the end of a launch says nothing about its steady state
+            else if (tune_window == 0 && now - tune_start >= kTuneSkipTicks) { tune_window = 1; tune_done = 0u; tune_start = now; }
+            else if (tune_window > 0 && now - tune_start >= kTuneWindowTicks) {
+                if (lane == 0u) {
+                    atomicAdd(&stats[kStatsTune + 2 * preset], (unsigned long long)tune_done);
+                    atomicAdd(&stats[kStatsTune + 2 * preset + 1], now - tune_start);
+                }
+                tune_done = 0u; tune_start = now;
+                if (++tune_window < 3) preset = 1;
+                else settle(true);
+            }
+        }
+        const int walk_vote = tune.vote[preset], rounds = tune.rounds[preset], steps = tune.steps[preset];
         // ---- subtrees that other lanes traced for this one; subtrees for idle lanes once there are no new items
 #ifdef SRT_TIMELINE
         if (dry) tl_trips++; else tl_trips += 1ull << 32;
 #endif
-        if (share != 0 && dry) {
-            if (!sharing) { open = open_children(ln, phase, frames, sc); sharing = true; }
+        if (share != 0 && (dry || __ballot(open != 0u || phase == LANE_DELIVER || phase == MESH_WAIT) != 0ull)) {
+            if (dry && !sharing) {
+                // from here on smaller subtrees change lanes too: look the pending frames over once (a lane that waits for a
+                // child holds its frame's node id instead of a child's and keeps the mask it has)
+                if (phase != MESH_WAIT) open = open_children(ln, phase, frames, sc) & ~fork.given;
+                sharing = true;
+            }
             rendezvous(ln, phase, fork, deliver, lane);
             if (share_open_children(ln, phase, frames, fork, open, deliver, my_pair, ra, lane, handed)) {
                 tr.d = ln.qd; tr.cur = TRAV_NEW; phase = MESH_CLOSEST;
@@ -619,6 +675,7 @@ __global__ void __launch_bounds__(kBlock, SRT_WAVES_PER_SIMD_MESH) mesh_trace_ke
                 if (!EXACT && __ballot(tr.pad != 0.0f) != 0ull) trav_run<EXACT, COUNT, 64, !EXACT>(sc, o, t_min, tr, my_stack, cnt, rounds, steps);
                 else trav_run<EXACT, COUNT, 64>(sc, o, t_min, tr, my_stack, cnt, rounds, steps);
             }
+            if (calibrating) tune_done += (uint32_t)__popcll(__ballot(walking && tr.cur == TRAV_NONE));
             prof.mark(PROF_CLOSEST);
         } else if (n_up >= n_closest && n_up >= n_shadow) {
             // ---- values travel up the tree; idle lanes take new items
@@ -773,7 +830,7 @@ static uint32_t resident_blocks(K kernel)
 }
 
 hipError_t launch_trace(const SceneView& sc, const RenderArgs& ra_in, bool exact, bool counted, float* d_samples,
-                        unsigned long long* d_stats, uint32_t* d_work_counter, float* d_timeline, hipStream_t stream)
+                        unsigned long long* d_stats, uint32_t* d_work_counter, float* d_timeline, hipStream_t stream, int walk_tune)
 {
     if (ra_in.n_items == 0u) return hipSuccess;
     RenderArgs ra = ra_in;
@@ -821,16 +878,28 @@ hipError_t launch_trace(const SceneView& sc, const RenderArgs& ra_in, bool exact
     const uint32_t guide = guide_knob != 0u ? blocks * (uint32_t)kWaves * guide_knob : 1u;   // 1: every draw is `chunk` items
     f3* s = reinterpret_cast<f3*>(d_samples);
     // Scenes whose tree is walked with a stack get the kernel that schedules traversal in quanta.
+    // SRT_WALK_* (experiments) replace preset 0 and switch the calibration off
+    static const bool walk_knobs = std::getenv("SRT_WALK_VOTE") || std::getenv("SRT_WALK_ROUNDS") || std::getenv("SRT_WALK_STEPS") || std::getenv("SRT_NO_WALK_TUNE");
     static const int walk_vote = std::getenv("SRT_WALK_VOTE") ? std::atoi(std::getenv("SRT_WALK_VOTE")) : kWalkVote;
     static const int walk_rounds = std::getenv("SRT_WALK_ROUNDS") ? std::atoi(std::getenv("SRT_WALK_ROUNDS")) : kWalkRounds;
     static const int walk_steps = std::getenv("SRT_WALK_STEPS") ? std::atoi(std::getenv("SRT_WALK_STEPS")) : kWalkSteps;
+    WalkTune tune;
+    tune.vote[0] = walk_vote; tune.rounds[0] = walk_rounds; tune.steps[0] = walk_steps;
+    tune.vote[1] = kShortVote; tune.rounds[1] = kShortRounds; tune.steps[1] = kShortSteps;
+    tune.mode = walk_knobs ? WALK_TUNE_LONG : walk_tune;
     static const bool allow_fork = !std::getenv("SRT_NO_SUBTREE_SHARING");
     float4* timeline = reinterpret_cast<float4*>(d_timeline);
     const int share = allow_fork && (uint32_t)ra.mode == MODE_COLOR ? 1 : 0;   // lanes share the last ray trees of a launch
     if (!stackless) {
-        static const uint32_t mesh_scatter = std::getenv("SRT_MESH_SCATTER_SAMPLES") ? (uint32_t)std::atoi(std::getenv("SRT_MESH_SCATTER_SAMPLES")) : 0u;
+        static const int steady_depth = std::getenv("SRT_STEADY_FORK_DEPTH") ? std::atoi(std::getenv("SRT_STEADY_FORK_DEPTH")) : kSteadyForkDepth;
+        // Scenes that want short quanta scatter their rays anyway: their samples are enumerated in scattered order, which
+        // spreads the deep ray trees of one screen region over many wavefronts (10,000-sphere scene: 518 -> 457 ms); for a
+        // single mesh a scattered sample costs 2.6 times a coherent one, so those keep the block order.
+        static const bool scatter_knob = std::getenv("SRT_MESH_SCATTER_SAMPLES") != nullptr;
+        static const uint32_t scatter_env = scatter_knob ? (uint32_t)std::atoi(std::getenv("SRT_MESH_SCATTER_SAMPLES")) : 0u;
+        const uint32_t mesh_scatter = scatter_knob ? scatter_env : (tune.mode == WALK_TUNE_SHORT ? kShortScatterSamples : 0u);
         set_item_order(ra, mesh_scatter);
-#define SRT_LAUNCH_MESH(E, C) hipLaunchKernelGGL((mesh_trace_kernel<E, C>), grid, block, 0, stream, sc, ra, s, d_stats, d_work_counter, timeline, walk_vote, walk_rounds, walk_steps, chunk, guide, share)
+#define SRT_LAUNCH_MESH(E, C) hipLaunchKernelGGL((mesh_trace_kernel<E, C>), grid, block, 0, stream, sc, ra, s, d_stats, d_work_counter, timeline, tune, chunk, guide, share, steady_depth)
         if (exact) { if (counted) SRT_LAUNCH_MESH(true, true); else SRT_LAUNCH_MESH(true, false); }
         else { if (counted) SRT_LAUNCH_MESH(false, true); else SRT_LAUNCH_MESH(false, false); }
 #undef SRT_LAUNCH_MESH

@@ -13,8 +13,19 @@ namespace srt {
 // d_stats: 48 x uint64 the kernel adds to: rays_path, rays_shadow, hit_nodes, box_tests, sphere_tests,
 // tri_tests, rect_tests, section counts, alarm; [16, 32) cycles per part, [32, 48) the same weighted by active lanes.  d_work_counter: one uint32, reset by the launcher on `stream`.
 // d_timeline: trace_timeline_bytes() of device memory; only -DSRT_TIMELINE builds write to it (per-wavefront clock records).
+// walk_tune (scenes whose tree is walked with a stack): which traversal quantum the kernel uses -- long, short, or
+// "measure both at the start of the launch and take the faster".  A calibrating launch adds what it measured to d_stats
+// words 12-15 (traversals finished, wall-clock ticks; preset 0 then 1); walk_tune_prefers_short() reads them.
+enum { WALK_TUNE_LONG = 0, WALK_TUNE_SHORT = 1, WALK_TUNE_CALIBRATE = 2 };
 hipError_t launch_trace(const SceneView& sc, const RenderArgs& ra, bool exact, bool counted, float* d_samples,
-                        unsigned long long* d_stats, uint32_t* d_work_counter, float* d_timeline, hipStream_t stream);
+                        unsigned long long* d_stats, uint32_t* d_work_counter, float* d_timeline, hipStream_t stream,
+                        int walk_tune = WALK_TUNE_LONG);
+// The decision rule, shared by the kernel and the host: short quanta must finish traversals at least 3 % faster.
+SRT_HD bool walk_tune_prefers_short(double done_long, double ticks_long, double done_short, double ticks_short)
+{
+    return done_short * ticks_long > 1.03 * done_long * ticks_short;
+}
+constexpr unsigned long long kWalkTuneEnoughTicks = 15000000ull;   // 50 wavefront windows of 3 ms (100 MHz wall clock) per preset
 // The address, on the current device `device`, of the library's static workspace of SRT_STATIC_SCRATCH_BYTES (the memory
 // srt_render_device_static works in).  Called once per device at set-up; allocates nothing.
 hipError_t static_scratch_setup(int device, unsigned char** ptr);

@@ -570,6 +570,9 @@ int srt_create(const srt_config* cfg, srt_ctx** out)
     }
     // RCCL refuses a communicator with one GPU in two ranks, and one device has nothing to gather
     c->gather = (ordinals.size() > 1 && distinct) ? gather : SRT_GATHER_PEER_COPY;
+    // SRT_RCCL_SINGLE=1 (tests on a box with one GPU): a list of one device makes its one-rank communicator all the same,
+    // which exercises loading librccl, ncclCommInitAll and the rank count check; there is still nothing to gather
+    if (ordinals.size() == 1 && n_cfg != 0 && gather == SRT_GATHER_RCCL && std::getenv("SRT_RCCL_SINGLE")) c->gather = SRT_GATHER_RCCL;
     if (ordinals.size() > 1) {
         // direct xGMI access between the first device and the others, where the platform offers it
         for (size_t i = 1; i < ordinals.size(); i++) {

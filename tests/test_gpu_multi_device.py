@@ -89,6 +89,19 @@ def test_a_device_list_of_one_with_rccl_requested_needs_no_communicator():
         srt.Renderer(devices=[99])
 
 
+def test_rccl_loads_and_makes_a_communicator(monkeypatch):
+    """The RCCL side of a several-device context on the one GPU of this box: librccl is found and bound at run time,
+    ncclCommInitAll makes a communicator and its rank count is the device count.  (Sends and receives need a second GPU.)"""
+    monkeypatch.setenv("SRT_RCCL_SINGLE", "1")
+    r = srt.Renderer(devices=[0], gather=srt.GATHER_RCCL)
+    assert r.device_info() == {"devices": [0], "gather": srt.GATHER_RCCL, "rccl_ranks": 1}
+    world, lights, cam = helpers.default_spec().host(64, 36)
+    r.set_scene(world, lights, cam)
+    img = r.render(64, 36, samples=1, max_depth=4, seed=1)
+    assert img.shape == (36, 64) and (img >> 24 == 255).all()
+    r.close()
+
+
 def test_launches_on_different_streams_are_ordered(single):
     """Launches of one context share its sample buffer and work counter: a launch on another stream has to wait for
     the one before it, or both pictures are wrong."""

@@ -106,7 +106,7 @@ struct srt_ctx {
     int world_kind = SRT_WORLD_BVHNODE;
     Camera cam{};
     bool has_camera = false;
-    uint64_t sample_budget = (uint64_t)2 << 30;  // bytes the sample buffer of a device may take (SRT_SAMPLE_BUFFER_MB)
+    uint64_t sample_budget = (uint64_t)8 << 30;  // bytes the sample buffer of a device may take (SRT_SAMPLE_BUFFER_MB); 8K at 1024 spp: 7.04 s with 2 GiB, 6.83 s with 8
     srt_stats stats{};
     // dev[0] only
     uint32_t* d_gathered = nullptr;       // several devices: every device's tile buffer, `stride` pixels apart

@@ -294,11 +294,10 @@ SRT_HD bool test_tri(q4 p0, q4 p1, float acz, bool flip, f3 o, f3 d, float t_min
     return true;
 }
 
+// The test of primitive `idx`, whose record (three words) the caller has already fetched.
 template <bool COUNT>
-SRT_HD void test_prim(const SceneView& sc, uint32_t idx, f3 o, f3 d, float a, float t_min, Hit& best, Counters& cnt)
+SRT_HD void test_prim_record(q4 p0, q4 p1, q4 p2, uint32_t idx, f3 o, f3 d, float a, float t_min, Hit& best, Counters& cnt)
 {
-    // all three words at once: one memory round trip per primitive, whatever its type turns out to be
-    q4 p0 = sc.prims[3 * idx], p1 = sc.prims[3 * idx + 1], p2 = sc.prims[3 * idx + 2];
     uint32_t info = fbits(p2.y), order = fbits(p2.z);
     uint32_t type = info & 3u;
     float t = 0.0f, u = 0.0f, v = 0.0f;
@@ -318,6 +317,12 @@ SRT_HD void test_prim(const SceneView& sc, uint32_t idx, f3 o, f3 d, float a, fl
     if (h && (t < best.t || best.prim == NO_PRIM || order >= best.order)) {
         best.t = t; best.prim = idx; best.u = u; best.v = v; best.order = order;
     }
+}
+template <bool COUNT>
+SRT_HD void test_prim(const SceneView& sc, uint32_t idx, f3 o, f3 d, float a, float t_min, Hit& best, Counters& cnt)
+{
+    // all three words at once: one memory round trip per primitive, whatever its type turns out to be
+    test_prim_record<COUNT>(sc.prims[3 * idx], sc.prims[3 * idx + 1], sc.prims[3 * idx + 2], idx, o, d, a, t_min, best, cnt);
 }
 
 // SurfaceList.hit (RaytracingClasses.cs:296-316) over every surface of the world, for the queries of a
@@ -409,14 +414,18 @@ SRT_HD Hit closest_hit(const SceneView& sc, f3 o, f3 d, float t_min, Counters& c
         for (uint32_t i = 0; i < sc.n_tiny; i++) {
             // fetch the next node while this one is tested (the array has one spare entry at the end)
             q4 m0 = sc.tiny[2 * i + 2], m1 = sc.tiny[2 * i + 3];
+            // a leaf's first primitive is fetched while its box is tested (uniform address: a scalar load whose latency the
+            // box test hides; node 0's descriptor says nothing about a primitive when the node is an inner one)
+            const uint32_t desc = fbits(n0.w);
+            const uint32_t first = (desc & DESC_LEAF) ? (desc & 0x07FFFFFFu) : 0u, count = ((desc >> 27) & 15u) + 1u;
+            const q4 r0 = sc.prims[3 * first], r1 = sc.prims[3 * first + 1], r2 = sc.prims[3 * first + 2];
             if (cur == i) {
                 if (COUNT) cnt.box_tests++;
                 if (box_hit_reference(n0, n1, o, inv)) {
                     cur = i + 1u;
-                    uint32_t desc = fbits(n0.w);
                     if (desc & DESC_LEAF) {
-                        uint32_t first = desc & 0x07FFFFFFu, count = ((desc >> 27) & 15u) + 1u;
-                        for (uint32_t k = 0; k < count; k++) test_prim<COUNT>(sc, first + k, o, d, a, t_min, best, cnt);
+                        test_prim_record<COUNT>(r0, r1, r2, first, o, d, a, t_min, best, cnt);
+                        for (uint32_t k = 1; k < count; k++) test_prim<COUNT>(sc, first + k, o, d, a, t_min, best, cnt);
                     }
                 } else {
                     cur = fbits(n1.w);  // first node after this subtree

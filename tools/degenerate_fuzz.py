@@ -8,6 +8,9 @@ Two families of random small scenes, each rendered for both world kinds:
   shading    the Game1 scene or a small mesh scene with materials outside [0, 1] or NaN, lights of zero, negative
              or 1e30 brightness, at the camera, inside a sphere or at infinity, no lights, sixteen lights, and
              cameras with a field of view of 0, 1, 179 or 200 degrees, looking along the up vector or nowhere.
+  far        helpers.far_camera_spec-like scenes: random spheres (radius 0.01 .. 2) and optionally a triangle mesh, seen
+             through a narrow lens from 10 .. 10^7 scene sizes away, where the float sphere test reports hits for rays that
+             miss by a wide margin and the library's tree must not cull them.
 A case passes when the image is within 1 LSB per channel of the oracle's and the ray counts are equal.
 --emu runs the kernel source on the CPU (tests/emu) instead of the GPU library.
 """
@@ -92,6 +95,28 @@ def shading_spec(seed):
     return s
 
 
+def far_spec(seed):
+    rng = np.random.default_rng(7000 + seed)
+    s = helpers.SceneSpec()
+    s.materials = [((0.8, 0.5, 0.5), 0.0, 0.5, (0, 0, 0)), ((0.6, 0.7, 0.9), 0.5, 0.8, (0, 0, 0))]
+    n = int(rng.integers(9, 40))
+    spread = float(rng.choice([1.0, 4.0, 20.0]))
+    s.spheres = [((f32(x), f32(y), f32(z)), f32(rad), int(rng.integers(0, 2)))
+                 for (x, y, z), rad in zip(rng.uniform(-spread, spread, (n, 3)), 10 ** rng.uniform(-2, 0.3, n))]
+    if rng.integers(0, 2):
+        p, nr = helpers.uv_sphere(tuple(rng.uniform(-spread, spread, 3)), float(rng.uniform(0.3, 2.0)), 6, 12)
+        s.meshes.append((p, nr, 1, False, True))
+    s.lights = [((0.0, -30.0 * spread, 0.0), 5.0, None)]
+    dist = float(10 ** rng.uniform(1, 7)) * spread
+    axis = int(rng.integers(0, 3))
+    o = [0.0, 0.0, 0.0]
+    o[axis] = dist * float(rng.choice([-1.0, 1.0]))
+    if rng.integers(0, 2):
+        o[(axis + 1) % 3] = 0.37 * dist
+    s.camera = (tuple(o), (0, 0, 0), float(np.degrees(2 * np.arctan(1.5 * spread / np.linalg.norm(o)))))
+    return s
+
+
 def main():
     n = int(sys.argv[1]) if len(sys.argv) > 1 and sys.argv[1].isdigit() else 100
     np.seterr(all="ignore")
@@ -102,8 +127,10 @@ def main():
     first = int(sys.argv[sys.argv.index("--first") + 1]) if "--first" in sys.argv else 0
     for seed in range(first, first + n):
         rng = np.random.default_rng(1000 + seed)
-        for family, spec in (("geometry", helpers.nasty_spec(seed)), ("shading", shading_spec(seed))):
+        for family, spec in (("geometry", helpers.nasty_spec(seed)), ("shading", shading_spec(seed)), ("far", far_spec(seed))):
             depth, spp, mode = int(rng.choice([0, 1, 3, 6, 9])), int(rng.choice([1, 2, 3])), int(rng.choice(modes))
+            if family == "far":
+                depth, mode = min(depth, 3), srt.MODE_COLOR
             if family == "shading":
                 depth = min(depth, 6)   # a camera that looks nowhere sends NaN rays: three children per level, every surface tested
             for kind in (srt.WORLD_SURFACELIST, srt.WORLD_BVHNODE):

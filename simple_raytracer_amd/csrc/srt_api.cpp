@@ -77,6 +77,7 @@ struct DeviceState {
     unsigned long long* d_stats = nullptr;
     uint32_t* d_counter = nullptr;        // work counter of the persistent trace kernel
     float* d_timeline = nullptr;          // scratch of -DSRT_TIMELINE builds (per-wavefront clock records)
+    void* d_frame_slab = nullptr;         // frames of pending ray-tree nodes, one part per wavefront of the grid
     float* d_samples = nullptr;           // per-(sample, pixel) colours of one pass, 12 bytes each
     size_t samples_capacity = 0;          // bytes
     float* d_running = nullptr;           // per-pixel running sums, only for renders that need several passes
@@ -348,7 +349,7 @@ int launch(srt_ctx* c, DeviceState& d, const srt_render_params* p, uint32_t* d_o
             ra.sample_first = (uint32_t)b;
             ra.sample_count = 1u;
             ra.n_items = ra.n_work;
-            hipError_t e = launch_trace(view, ra, exact, counted, ws.samples, d.d_stats, ws.counter, d.d_timeline, stream, d.walk_tune);
+            hipError_t e = launch_trace(view, ra, exact, counted, ws.samples, d.d_stats, ws.counter, d.d_timeline, d.d_frame_slab, stream, d.walk_tune);
             if (e != hipSuccess) return hip_fail(c, e, "trace kernel launch");
             e = launch_resolve(ra, ws.samples, ws.running, c->d_mix, true, true, 0.0f, stream);
             if (e != hipSuccess) return hip_fail(c, e, "resolve kernel launch");
@@ -364,7 +365,7 @@ int launch(srt_ctx* c, DeviceState& d, const srt_render_params* p, uint32_t* d_o
         ra.sample_first = s0;
         ra.sample_count = (uint32_t)ra.samples - s0 < (uint32_t)per_pass ? (uint32_t)ra.samples - s0 : (uint32_t)per_pass;
         ra.n_items = ra.n_work * ra.sample_count;
-        hipError_t e = launch_trace(view, ra, exact, counted, ws.samples, d.d_stats, ws.counter, d.d_timeline, stream, d.walk_tune);
+        hipError_t e = launch_trace(view, ra, exact, counted, ws.samples, d.d_stats, ws.counter, d.d_timeline, d.d_frame_slab, stream, d.walk_tune);
         if (e != hipSuccess) return hip_fail(c, e, "trace kernel launch");
         const uint32_t done = s0 + ra.sample_count;
         const float preview = progressive ? (float)ra.samples / (float)done : 0.0f;
@@ -495,6 +496,7 @@ int create_device(DeviceState& d, int ordinal)
 #ifdef SRT_TIMELINE
               hipMalloc((void**)&d.d_timeline, trace_timeline_bytes()) == hipSuccess &&
 #endif
+              hipMalloc(&d.d_frame_slab, trace_frame_slab_bytes()) == hipSuccess &&
               hipMemset(d.d_stats, 0, kStatsWords * sizeof(unsigned long long)) == hipSuccess && hipDeviceSynchronize() == hipSuccess &&
               static_scratch_setup(ordinal, &d.static_scratch) == hipSuccess;
     return ok ? SRT_OK : SRT_E_HIP;
@@ -509,6 +511,7 @@ void destroy_device(DeviceState& d)
     if (d.d_stats) hipFree(d.d_stats);
     if (d.d_counter) hipFree(d.d_counter);
     if (d.d_timeline) hipFree(d.d_timeline);
+    if (d.d_frame_slab) hipFree(d.d_frame_slab);
     if (d.d_samples) hipFree(d.d_samples);
     if (d.d_running) hipFree(d.d_running);
     if (d.ev_begin) hipEventDestroy(d.ev_begin);

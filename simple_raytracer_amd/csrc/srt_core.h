@@ -198,19 +198,34 @@ enum { STACK_DEPTH = 36, MAX_LEAF_PRIMS = 16, FRAME_SLOTS = 16, TINY_TREE_NODES 
 // Triangle normals, 3 words per triangle: (nA.xyz -) (nB.xyz -) (nC.xyz -).
 // Material, 2 words: (albedo.xyz metalness) (smoothness emission.xyz).
 // Light, 2 words: (position.xyz brightness) (color.xyz -).
+// Scene tables that the kernels read with wave-uniform indices (nodes, the primitives of a leaf, lights).  Device code
+// sees them in the constant address space: no kernel ever writes a scene table, and only with that stated in the
+// pointer type do uniform reads stay scalar loads in a kernel that also stores to other global memory (the compiler
+// cannot prove that those stores leave the tables alone, and falls back to vector loads plus readfirstlane).
+#if defined(__HIP_DEVICE_COMPILE__)
+typedef float table_f4 __attribute__((ext_vector_type(4)));
+typedef const __attribute__((address_space(4))) table_f4* scene_table;
+SRT_HD scene_table as_scene_table(const q4* p) { return (scene_table)p; }
+SRT_HD q4 table_word(scene_table t, uint32_t i) { const table_f4 v = t[i]; q4 r; r.x = v.x; r.y = v.y; r.z = v.z; r.w = v.w; return r; }
+#else
+typedef const q4* scene_table;
+SRT_HD scene_table as_scene_table(const q4* p) { return p; }
+SRT_HD q4 table_word(scene_table t, uint32_t i) { return t[i]; }
+#endif
+
 struct SceneView {
-    const q4* nodes;
-    const q4* prims;
-    const q4* normals;
+    scene_table nodes;
+    scene_table prims;
+    scene_table normals;
     const q4* materials;
-    const q4* lights;
+    scene_table lights;
     uint32_t n_lights;
     uint32_t list_first, list_count;  // primitives scanned linearly (rects; everything in tiny scenes)
     uint32_t has_bvh;                 // nodes[0] is the root when set
     uint32_t n_wide;                  // non-zero: `nodes` holds that many 64-byte wide nodes (4 words each) instead
     // Small reference trees only: the same nodes in depth-first (pre)order, 2 words each:
     // (min.xyz, desc) (max.xyz, index of the first node after this node's subtree).
-    const q4* tiny;
+    scene_table tiny;
     uint32_t n_tiny;
     uint32_t n_nodes, n_prims, n_materials;  // table sizes (nodes / primitive records / materials)
     // The primitive records again, for the per-lane lookups of the winning hit (same data as `prims`; the kernels
@@ -322,7 +337,7 @@ template <bool COUNT>
 SRT_HD void test_prim(const SceneView& sc, uint32_t idx, f3 o, f3 d, float a, float t_min, Hit& best, Counters& cnt)
 {
     // all three words at once: one memory round trip per primitive, whatever its type turns out to be
-    test_prim_record<COUNT>(sc.prims[3 * idx], sc.prims[3 * idx + 1], sc.prims[3 * idx + 2], idx, o, d, a, t_min, best, cnt);
+    test_prim_record<COUNT>(table_word(sc.prims, 3 * idx), table_word(sc.prims, 3 * idx + 1), table_word(sc.prims, 3 * idx + 2), idx, o, d, a, t_min, best, cnt);
 }
 
 // SurfaceList.hit (RaytracingClasses.cs:296-316) over every surface of the world, for the queries of a
@@ -351,7 +366,7 @@ SRT_HD Hit scan_all_surfaces(const SceneView& sc, f3 o, f3 d, float a, float t_m
     const bool after = best.prim != NO_PRIM;
     const uint32_t last_nan = best.order;
     for (uint32_t i = 0; i < sc.n_prims; i++) {
-        if (after && fbits(sc.prims[3 * i + 2].z) <= last_nan) continue;
+        if (after && fbits(table_word(sc.prims, 3 * i + 2).z) <= last_nan) continue;
         test_prim<COUNT>(sc, i, o, d, a, t_min, best, cnt);
     }
     return best;
@@ -410,15 +425,15 @@ SRT_HD Hit closest_hit(const SceneView& sc, f3 o, f3 d, float t_min, Counters& c
         // per-lane gathers, no stack), and the visit order, box semantics and tie-breaks are BVHNode.hit's.
         const f3 inv = mk3(1.0f / d.x, 1.0f / d.y, 1.0f / d.z);
         uint32_t cur = 0u;
-        q4 n0 = sc.tiny[0], n1 = sc.tiny[1];
+        q4 n0 = table_word(sc.tiny, 0), n1 = table_word(sc.tiny, 1);
         for (uint32_t i = 0; i < sc.n_tiny; i++) {
             // fetch the next node while this one is tested (the array has one spare entry at the end)
-            q4 m0 = sc.tiny[2 * i + 2], m1 = sc.tiny[2 * i + 3];
+            q4 m0 = table_word(sc.tiny, 2 * i + 2), m1 = table_word(sc.tiny, 2 * i + 3);
             // a leaf's first primitive is fetched while its box is tested (uniform address: a scalar load whose latency the
             // box test hides; node 0's descriptor says nothing about a primitive when the node is an inner one)
             const uint32_t desc = fbits(n0.w);
             const uint32_t first = (desc & DESC_LEAF) ? (desc & 0x07FFFFFFu) : 0u, count = ((desc >> 27) & 15u) + 1u;
-            const q4 r0 = sc.prims[3 * first], r1 = sc.prims[3 * first + 1], r2 = sc.prims[3 * first + 2];
+            const q4 r0 = table_word(sc.prims, 3 * first), r1 = table_word(sc.prims, 3 * first + 1), r2 = table_word(sc.prims, 3 * first + 2);
             if (cur == i) {
                 if (COUNT) cnt.box_tests++;
                 if (box_hit_reference(n0, n1, o, inv)) {
@@ -462,10 +477,11 @@ SRT_HD float wide_child(uint32_t nx, uint32_t ny, uint32_t nz, uint32_t fx, uint
     float n1 = __builtin_fmaf((float)((nx >> shift) & 255u), A.x, Bn.x), f1 = __builtin_fmaf((float)((fx >> shift) & 255u), A.x, Bf.x);
     float n2 = __builtin_fmaf((float)((ny >> shift) & 255u), A.y, Bn.y), f2 = __builtin_fmaf((float)((fy >> shift) & 255u), A.y, Bf.y);
     float n3 = __builtin_fmaf((float)((nz >> shift) & 255u), A.z, Bn.z), f3_ = __builtin_fmaf((float)((fz >> shift) & 255u), A.z, Bf.z);
-    float tmin = max2(max2(n1, n2), n3);
-    float tmax = min2(min2(f1, f2), f3_);
-    bool hit = !((tmax < 0.0f) | (tmin > tmax) | (tmin > t_best));
-    return hit ? max2(tmin, -3.0e38f) : INFINITY;
+    // entry distance clamped to the ray's start, exit distance to the closest hit so far: one compare decides
+    // (tmax < 0, tmin > tmax and tmin > t_best at once)
+    float tmin = max2(max2(max2(n1, n2), n3), 0.0f);
+    float tmax = min2(min2(min2(f1, f2), f3_), t_best);
+    return tmin > tmax ? INFINITY : tmin;
 }
 SRT_HD void sort_pair(float& ta, uint32_t& ca, float& tb, uint32_t& cb)
 {
@@ -512,7 +528,7 @@ SRT_HD void trav_begin(const SceneView& sc, f3 o, float t_min, Trav& tr, uint32_
     }
     if (EXACT) {
         const f3 inv = mk3(1.0f / d.x, 1.0f / d.y, 1.0f / d.z);
-        q4 r0 = sc.nodes[0], r1 = sc.nodes[1];
+        q4 r0 = table_word(sc.nodes, 0), r1 = table_word(sc.nodes, 1);
         if (COUNT) cnt.box_tests++;
         tr.cur = box_hit_reference(r0, r1, o, inv) ? fbits(r0.w) : (uint32_t)TRAV_NONE;
     } else {
@@ -535,8 +551,8 @@ SRT_HD void trav_run(const SceneView& sc, f3 o, float t_min, Trav& tr, uint32_t*
         for (int s = 0; s < steps && !(cur & DESC_LEAF); s++) {
             if (EXACT) {
                 // the reference tree: two adjacent children, left subtree first, no distance culling
-                q4 l0 = sc.nodes[2 * cur], l1 = sc.nodes[2 * cur + 1];
-                q4 h0 = sc.nodes[2 * cur + 2], h1 = sc.nodes[2 * cur + 3];
+                q4 l0 = table_word(sc.nodes, 2 * cur), l1 = table_word(sc.nodes, 2 * cur + 1);
+                q4 h0 = table_word(sc.nodes, 2 * cur + 2), h1 = table_word(sc.nodes, 2 * cur + 3);
                 if (COUNT) cnt.box_tests += 2;
                 uint32_t dl = fbits(l0.w), dr = fbits(h0.w);
                 bool hl = box_hit_reference(l0, l1, o, inv);
@@ -546,7 +562,7 @@ SRT_HD void trav_run(const SceneView& sc, f3 o, float t_min, Trav& tr, uint32_t*
                 else cur = st.sp == 0 ? (uint32_t)TRAV_NONE : st.pop();
             } else {
                 // a wide node: up to four quantised child boxes, nearest first, the others pushed far to near
-                q4 w0 = sc.nodes[4 * cur], w1 = sc.nodes[4 * cur + 1], w2 = sc.nodes[4 * cur + 2], w3 = sc.nodes[4 * cur + 3];
+                q4 w0 = table_word(sc.nodes, 4 * cur), w1 = table_word(sc.nodes, 4 * cur + 1), w2 = table_word(sc.nodes, 4 * cur + 2), w3 = table_word(sc.nodes, 4 * cur + 3);
                 uint32_t meta = fbits(w0.w);
                 uint32_t nk = meta >> 24;
                 if (COUNT) cnt.box_tests += nk;
@@ -617,7 +633,7 @@ SRT_HD HitRecord resolve_hit(const SceneView& sc, const Hit& h, f3 o, f3 d)
         f3 n;
         if (info & INFO_BLEND) {
             uint32_t ni = fbits(p2.w);
-            q4 a = sc.normals[3 * ni], b = sc.normals[3 * ni + 1], c = sc.normals[3 * ni + 2];
+            q4 a = table_word(sc.normals, 3 * ni), b = table_word(sc.normals, 3 * ni + 1), c = table_word(sc.normals, 3 * ni + 2);
             // Vector3.Barycentric: a + (b - a) u + (c - a) v per component
             n = mk3(a.x + (b.x - a.x) * h.u + (c.x - a.x) * h.v, a.y + (b.y - a.y) * h.u + (c.y - a.y) * h.v,
                     a.z + (b.z - a.z) * h.u + (c.z - a.z) * h.v);
@@ -669,7 +685,7 @@ SRT_HD float fresnel_term(f3 dir, f3 reflected)
 struct Light { f3 position; float brightness; f3 color; };
 SRT_HD Light load_light(const SceneView& sc, uint32_t i)
 {
-    q4 a = sc.lights[2 * i], b = sc.lights[2 * i + 1];
+    q4 a = table_word(sc.lights, 2 * i), b = table_word(sc.lights, 2 * i + 1);
     Light l;
     l.position = mk3(a.x, a.y, a.z); l.brightness = a.w; l.color = mk3(b.x, b.y, b.z);
     return l;

@@ -234,6 +234,13 @@ constexpr int kLdsFrameLevels = 3;
 constexpr uint32_t kSmallPrimWords = 3 * kSmallPrims, kSmallMatWords = 2 * kSmallMaterials;
 constexpr uint32_t kSmallWords = kSmallPrimWords + kSmallMatWords;
 
+// Byte offset, in the frame slab, of the level-0 frame of this lane: every wavefront of the grid owns FRAME_SLOTS levels
+// of 64 frames.
+__device__ __forceinline__ uint32_t my_frame_offset(uint32_t wave, uint32_t lane)
+{
+    return (blockIdx.x * (uint32_t)kWaves + wave) * (uint32_t)(FRAME_SLOTS * FRAME_SLAB_LEVEL_BYTES) + lane * 64u;
+}
+
 __device__ __forceinline__ void copy_words(q4* dst, const q4* src, uint32_t n)
 {
     for (uint32_t i = threadIdx.x; i < n; i += kBlock) dst[i] = src[i];
@@ -242,7 +249,7 @@ __device__ __forceinline__ void copy_words(q4* dst, const q4* src, uint32_t n)
 template <bool EXACT, bool COUNT, bool SMALL>
 __global__ void __launch_bounds__(kBlock, SMALL ? SRT_WAVES_PER_SIMD : SRT_WAVES_PER_SIMD_BIG) trace_kernel(SceneView gsc, RenderArgs ra, f3* __restrict__ samples,
                                                        unsigned long long* __restrict__ stats, uint32_t* __restrict__ work_counter,
-                                                       float4* __restrict__ timeline /* -DSRT_TIMELINE builds only */, int trace_vote, uint32_t chunk, int share, uint32_t guide)
+                                                       float4* __restrict__ timeline /* -DSRT_TIMELINE builds only */, q4* __restrict__ frame_slab, int trace_vote, uint32_t chunk, int share, uint32_t guide)
 {
     __shared__ float lds_frames[SMALL ? kWaves * kLdsFrameLevels * 14 * 64 : 1];
     __shared__ uint32_t lds_pair[kWaves * 64];   // handing over subtrees: giver lane by rank
@@ -257,7 +264,7 @@ __global__ void __launch_bounds__(kBlock, SMALL ? SRT_WAVES_PER_SIMD : SRT_WAVES
         // keep them in SGPRs instead of spending a VGPR per value.
         q4* prims = small_tables;
         q4* mats = prims + kSmallPrimWords;
-        copy_words(prims, gsc.prims, 3u * gsc.n_prims);
+        copy_words(prims, gsc.hit_prims, 3u * gsc.n_prims);
         copy_words(mats, gsc.materials, 2u * gsc.n_materials);
         sc.hit_prims = prims; sc.materials = mats;
     }
@@ -268,11 +275,14 @@ __global__ void __launch_bounds__(kBlock, SMALL ? SRT_WAVES_PER_SIMD : SRT_WAVES
     unsigned long long tl_dry = 0ull, tl_trips = 0ull;
 #endif
     Lane ln;
-    Frame frame_mem[FRAME_SLOTS];
-    typename std::conditional<SMALL, HybridFrames<kLdsFrameLevels>, PrivateFrames>::type frames;
-    frames.a = frame_mem;
+    typename std::conditional<SMALL, HybridFrames<kLdsFrameLevels>, SlabFrames>::type frames;
     if constexpr (SMALL) {
+        frames.deep.slab = reinterpret_cast<char*>(frame_slab);
+        frames.deep.mine = my_frame_offset(wave, lane);
         frames.lds = &lds_frames[wave * (kLdsFrameLevels * 14 * 64) + lane];
+    } else {
+        frames.slab = reinterpret_cast<char*>(frame_slab);
+        frames.mine = my_frame_offset(wave, lane);
     }
     Counters cnt;
     cnt.box_tests = cnt.sphere_tests = cnt.tri_tests = cnt.rect_tests = 0u;
@@ -521,7 +531,7 @@ struct WalkTune { int vote[2], rounds[2], steps[2]; int mode; };   // mode: WALK
 template <bool EXACT, bool COUNT>
 __global__ void __launch_bounds__(kBlock, SRT_WAVES_PER_SIMD_MESH) mesh_trace_kernel(SceneView sc, RenderArgs ra, f3* __restrict__ samples,
                                                             unsigned long long* __restrict__ stats, uint32_t* __restrict__ work_counter,
-                                                            float4* __restrict__ timeline /* -DSRT_TIMELINE builds only */, WalkTune tune, uint32_t chunk, uint32_t guide, int share,
+                                                            float4* __restrict__ timeline /* -DSRT_TIMELINE builds only */, q4* __restrict__ frame_slab, WalkTune tune, uint32_t chunk, uint32_t guide, int share,
                                                             int steady_depth)
 {
     __shared__ uint32_t lds_stack[kWaves * STACK_DEPTH * 64];
@@ -537,9 +547,9 @@ __global__ void __launch_bounds__(kBlock, SRT_WAVES_PER_SIMD_MESH) mesh_trace_ke
     unsigned long long tl_dry = 0ull, tl_trips = 0ull;
 #endif
     Lane ln;
-    Frame frame_mem[FRAME_SLOTS];
-    PrivateFrames frames;
-    frames.a = frame_mem;
+    SlabFrames frames;
+    frames.slab = reinterpret_cast<char*>(frame_slab);
+    frames.mine = my_frame_offset(wave, lane);
     Trav tr;
     tr.d = mk3(0.0f, 0.0f, 0.0f);
     tr.best.t = INFINITY; tr.best.prim = NO_PRIM; tr.best.u = tr.best.v = 0.0f; tr.best.order = 0u;
@@ -830,9 +840,11 @@ static uint32_t resident_blocks(K kernel)
 }
 
 hipError_t launch_trace(const SceneView& sc, const RenderArgs& ra_in, bool exact, bool counted, float* d_samples,
-                        unsigned long long* d_stats, uint32_t* d_work_counter, float* d_timeline, hipStream_t stream, int walk_tune)
+                        unsigned long long* d_stats, uint32_t* d_work_counter, float* d_timeline, void* d_frame_slab, hipStream_t stream, int walk_tune)
 {
     if (ra_in.n_items == 0u) return hipSuccess;
+    if (d_frame_slab == nullptr || d_samples == nullptr || d_stats == nullptr || d_work_counter == nullptr) return hipErrorInvalidValue;
+    q4* const slab = reinterpret_cast<q4*>(d_frame_slab);
     RenderArgs ra = ra_in;
     set_item_order(ra, 0u);
     hipError_t e = hipMemsetAsync(d_work_counter, 0, sizeof(uint32_t), stream);
@@ -899,7 +911,7 @@ hipError_t launch_trace(const SceneView& sc, const RenderArgs& ra_in, bool exact
         static const uint32_t scatter_env = scatter_knob ? (uint32_t)std::atoi(std::getenv("SRT_MESH_SCATTER_SAMPLES")) : 0u;
         const uint32_t mesh_scatter = scatter_knob ? scatter_env : (tune.mode == WALK_TUNE_SHORT ? kShortScatterSamples : 0u);
         set_item_order(ra, mesh_scatter);
-#define SRT_LAUNCH_MESH(E, C) hipLaunchKernelGGL((mesh_trace_kernel<E, C>), grid, block, 0, stream, sc, ra, s, d_stats, d_work_counter, timeline, tune, chunk, guide, share, steady_depth)
+#define SRT_LAUNCH_MESH(E, C) hipLaunchKernelGGL((mesh_trace_kernel<E, C>), grid, block, 0, stream, sc, ra, s, d_stats, d_work_counter, timeline, slab, tune, chunk, guide, share, steady_depth)
         if (exact) { if (counted) SRT_LAUNCH_MESH(true, true); else SRT_LAUNCH_MESH(true, false); }
         else { if (counted) SRT_LAUNCH_MESH(false, true); else SRT_LAUNCH_MESH(false, false); }
 #undef SRT_LAUNCH_MESH
@@ -912,7 +924,7 @@ hipError_t launch_trace(const SceneView& sc, const RenderArgs& ra_in, bool exact
     // short passes are better off with more of them: measured 5.83 -> 5.29 ms at 4 spp (all four), 9.14 -> 8.80 ms at 8 spp (three)
     const bool knob = std::getenv("SRT_SCATTER_SAMPLES") != nullptr;
     set_item_order(ra, knob ? scatter_samples : (ra.sample_count <= 4u ? ra.sample_count : (ra.sample_count <= 11u ? 3u : scatter_samples)));
-#define SRT_LAUNCH(E, C, S) hipLaunchKernelGGL((trace_kernel<E, C, S>), grid, block, 0, stream, sc, ra, s, d_stats, d_work_counter, timeline, vote, chunk, share, guide)
+#define SRT_LAUNCH(E, C, S) hipLaunchKernelGGL((trace_kernel<E, C, S>), grid, block, 0, stream, sc, ra, s, d_stats, d_work_counter, timeline, slab, vote, chunk, share, guide)
     if (exact) {
         if (counted) { if (small) SRT_LAUNCH(true, true, true); else SRT_LAUNCH(true, true, false); }
         else { if (small) SRT_LAUNCH(true, false, true); else SRT_LAUNCH(true, false, false); }
@@ -924,6 +936,9 @@ hipError_t launch_trace(const SceneView& sc, const RenderArgs& ra_in, bool exact
     return hipGetLastError();
 }
 
+// Every wavefront of the largest grid owns FRAME_SLOTS levels of 64 frames of 64 bytes.
+size_t trace_frame_slab_bytes() { return (size_t)kMaxBlocks * kWaves * FRAME_SLOTS * FRAME_SLAB_LEVEL_BYTES; }
+static_assert((unsigned long long)kMaxBlocks * kWaves * FRAME_SLOTS * FRAME_SLAB_LEVEL_BYTES < (1ull << 32), "frame offsets are 32-bit");
 size_t trace_timeline_records() { return (size_t)kMaxBlocks * kWaves; }
 size_t trace_timeline_offset() { return (size_t)1100 * kWaves * kTimelinePerWave * sizeof(float4); }
 size_t trace_timeline_bytes() { return (size_t)kMaxBlocks * kWaves * kTimelinePerWave * sizeof(float4); }

@@ -85,13 +85,18 @@ SRT_HD bool item_start(Lane& ln, const RenderArgs& ra, uint32_t item, const floa
     return true;
 }
 
-// Where the frames of pending parents live.  Both stores hold the same Frame per level; they differ in the memory
+// Where the frames of pending parents live.  All stores hold the same Frame per level; they differ in the memory
 // behind a level.
-//   PrivateFrames   an array in private memory (the CPU harness, and GPU scenes that need their LDS for traversal);
+//   PrivateFrames   an array in private memory (the CPU harness);
+//   SlabFrames      a slab of device memory, [wavefront][level][lane][64 bytes]: a frame is one whole 64-byte segment
+//                   of its own, written with four 16-byte stores.  Private memory interleaves the lanes word by word,
+//                   so a push by a few lanes of a wavefront dirties 14 different segments of which it fills 4 bytes each,
+//                   and what the caches write back is several times the frames' size; here a push writes the bytes of
+//                   the frames pushed, whatever lanes take part.
 //   HybridFrames    the first LDS_LEVELS levels of the recursion in LDS (the depth heuristic ends most branches of the
 //                   ray tree after a few levels, so more than half of all pushes and pops are there), laid out
 //                   [level][field][lane] so that the 64 lanes of a wavefront hit 64 different banks; deeper levels in
-//                   private memory.
+//                   the slab.
 struct PrivateFrames {
     Frame* a;
     SRT_HD Frame load(int32_t level) const { return a[level]; }
@@ -99,13 +104,48 @@ struct PrivateFrames {
     SRT_HD void store_acc(int32_t level, f3 acc) const { a[level].acc = acc; }
 };
 
+enum { FRAME_SLAB_LEVEL_BYTES = 64 * 64 };   // between two levels of a lane: 64 lanes x 64 bytes
+struct SlabFrames {
+    char* slab;      // the whole slab (the same pointer on every lane, so it can live in scalar registers)
+    uint32_t mine;   // byte offset of this lane's frame of level 0
+    SRT_HD q4* at(int32_t level) const { return reinterpret_cast<q4*>(slab + (mine + (uint32_t)level * (uint32_t)FRAME_SLAB_LEVEL_BYTES)); }
+    SRT_HD Frame load(int32_t level) const
+    {
+        const q4* p = at(level);
+        const q4 a = p[0], b = p[1], c = p[2], d = p[3];
+        Frame f;
+        f.acc = mk3(a.x, a.y, a.z);
+        f.light = mk3(a.w, b.x, b.y);
+        f.point = mk3(b.z, b.w, c.x);
+        f.refl = mk3(c.y, c.z, c.w);
+        f.w_refl = d.x;
+        f.meta = fbits(d.y);
+        return f;
+    }
+    SRT_HD void store(int32_t level, const Frame& f) const
+    {
+        q4* p = at(level);
+        q4 a, b, c, d;
+        a.x = f.acc.x; a.y = f.acc.y; a.z = f.acc.z; a.w = f.light.x;
+        b.x = f.light.y; b.y = f.light.z; b.z = f.point.x; b.w = f.point.y;
+        c.x = f.point.z; c.y = f.refl.x; c.z = f.refl.y; c.w = f.refl.z;
+        d.x = f.w_refl; d.y = bitsf(f.meta); d.z = 0.0f; d.w = 0.0f;
+        p[0] = a; p[1] = b; p[2] = c; p[3] = d;
+    }
+    SRT_HD void store_acc(int32_t level, f3 acc) const
+    {
+        float* p = reinterpret_cast<float*>(at(level));
+        p[0] = acc.x; p[1] = acc.y; p[2] = acc.z;
+    }
+};
+
 template <int LDS_LEVELS>
 struct HybridFrames {
-    Frame* a;          // private memory, all levels
+    SlabFrames deep;   // levels LDS_LEVELS and up, at slab level (level - LDS_LEVELS)
     float* lds;        // this lane's column of the wavefront's LDS slab
     SRT_HD Frame load(int32_t level) const
     {
-        if (level >= LDS_LEVELS) return a[level];
+        if (level >= LDS_LEVELS) return deep.load(level - LDS_LEVELS);
         const float* p = lds + level * (14 * 64);
         Frame f;
         f.acc = mk3(p[0 * 64], p[1 * 64], p[2 * 64]);
@@ -118,7 +158,7 @@ struct HybridFrames {
     }
     SRT_HD void store(int32_t level, const Frame& f) const
     {
-        if (level >= LDS_LEVELS) { a[level] = f; return; }
+        if (level >= LDS_LEVELS) { deep.store(level - LDS_LEVELS, f); return; }
         float* p = lds + level * (14 * 64);
         p[0 * 64] = f.acc.x; p[1 * 64] = f.acc.y; p[2 * 64] = f.acc.z;
         p[3 * 64] = f.light.x; p[4 * 64] = f.light.y; p[5 * 64] = f.light.z;
@@ -129,7 +169,7 @@ struct HybridFrames {
     }
     SRT_HD void store_acc(int32_t level, f3 acc) const
     {
-        if (level >= LDS_LEVELS) { a[level].acc = acc; return; }
+        if (level >= LDS_LEVELS) { deep.store_acc(level - LDS_LEVELS, acc); return; }
         float* p = lds + level * (14 * 64);
         p[0 * 64] = acc.x; p[1 * 64] = acc.y; p[2 * 64] = acc.z;
     }

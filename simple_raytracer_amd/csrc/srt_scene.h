@@ -46,7 +46,8 @@ struct FlatScene {
     SceneView view(const q4* d_nodes, const q4* d_prims, const q4* d_normals, const q4* d_materials, const q4* d_lights, const q4* d_tiny) const
     {
         SceneView v;
-        v.nodes = d_nodes; v.prims = d_prims; v.normals = d_normals; v.materials = d_materials; v.lights = d_lights; v.tiny = d_tiny;
+        v.nodes = as_scene_table(d_nodes); v.prims = as_scene_table(d_prims); v.normals = as_scene_table(d_normals); v.materials = d_materials;
+        v.lights = as_scene_table(d_lights); v.tiny = as_scene_table(d_tiny);
         v.n_lights = n_lights; v.list_first = list_first; v.list_count = list_count; v.has_bvh = has_bvh; v.n_tiny = n_tiny;
         v.n_nodes = n_nodes; v.n_prims = n_prims; v.n_materials = n_materials; v.n_wide = n_wide;
         v.hit_prims = d_prims;

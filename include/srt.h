@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define SRT_VERSION 200
+#define SRT_VERSION 201
 
 enum {
     SRT_OK = 0,
@@ -137,7 +137,8 @@ typedef struct {
 
 typedef struct {
     uint64_t rays_path;      /* GetRayColor calls with depth >= 1: primary + bounce rays */
-    uint64_t rays_shadow;    /* shadow rays, RaytracingClasses.cs:174 */
+    uint64_t rays_shadow;    /* shadow rays, RaytracingClasses.cs:174: one per light of every hit node, including those the
+                                library answers without a traversal (shadow_unasked) */
     uint64_t hit_nodes;      /* GetRayColor calls that hit a surface */
     uint64_t box_tests;      /* BVH nodes whose box was tested   (only filled by srt_render_counted) */
     uint64_t sphere_tests, tri_tests, rect_tests;   /* (only filled by srt_render_counted) */
@@ -154,7 +155,9 @@ typedef struct {
     /* Shader-clock cycles summed over wavefronts (only filled by srt_render_counted), by part of the kernel:
        0 dealing work items, 1 handing values up the tree, 2 closest-hit query, 3 bookkeeping after it,
        4 random words of a lit node, 5 shadow-ray set-up, 6 shadow query, 7 light evaluation,
-       8 child directions, 9 fresnel, 10 starting a child / finishing a leaf; 11-14 unused;
+       8 child directions, 9 fresnel, 10 starting a child / finishing a leaf;
+       11-14 (stackless scenes) how the launch ended, in 100 MHz ticks a wavefront kept running after the work ran out:
+       the longest, the sum, the wavefronts above 250 us, those above 1 ms;
        15 is a count, not cycles: subtrees that lanes handed to idle lanes of their wavefront (mesh scenes). */
     uint64_t section_cycles[16];
     /* Lane-cycles (only filled by srt_render_counted; stackless scenes): slots 0-10 as above but summed over the 64 lanes
@@ -162,6 +165,11 @@ typedef struct {
        other lanes of the wavefront to finish handing values up / taking new items / their closest-hit part / their
        light part.  Slots 0-10 over the sum of 0-14 is the share of lane time that did work. */
     uint64_t section_lane_cycles[16];
+    /* Shadow rays answered without a traversal (only filled by srt_render_counted; part of rays_shadow).  Scenes whose
+       tree is walked with a stack leave out the shadow ray of a light behind the surface when every factor of
+       PointLight.calculateLight is finite: with NdotL = 0 (RaytracingClasses.cs:113) the diffuse and the specular term
+       (:160-161, :185) are zero whatever the ray meets, so the result is the reference's bit for bit. */
+    uint64_t shadow_unasked;
 } srt_stats;
 
 typedef struct srt_ctx srt_ctx;

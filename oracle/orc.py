@@ -52,7 +52,9 @@ class Stats(C.Structure):
     _fields_ = [("rays_path", C.c_uint64), ("rays_shadow", C.c_uint64), ("rays_redundant", C.c_uint64), ("box_tests", C.c_uint64),
                 ("sphere_tests", C.c_uint64), ("tri_tests", C.c_uint64), ("rect_tests", C.c_uint64), ("hit_nodes", C.c_uint64),
                 ("seconds", C.c_double), ("threads_used", C.c_int32), ("reserved", C.c_int32),
-                ("box_repeats", C.c_uint64), ("sphere_repeats", C.c_uint64), ("tri_repeats", C.c_uint64), ("rect_repeats", C.c_uint64)]
+                ("box_repeats", C.c_uint64), ("sphere_repeats", C.c_uint64), ("tri_repeats", C.c_uint64), ("rect_repeats", C.c_uint64),
+                ("shadow_inert", C.c_uint64), ("box_inert", C.c_uint64), ("sphere_inert", C.c_uint64), ("tri_inert", C.c_uint64),
+                ("rect_inert", C.c_uint64)]
 
 
 def build(force=False):

@@ -233,16 +233,22 @@ struct Counters {
     // the part of the four *_tests above that repeats a test whose answer is already known: everything inside a
     // per-light re-intersection (RaytracingClasses.cs:211) and the second test of a single-surface leaf (:362-365)
     uint64_t box_repeats = 0, sphere_repeats = 0, tri_repeats = 0, rect_repeats = 0;
+    // shadow rays that cannot change what PointLight.calculateLight returns (see there), and the tests of their
+    // traversals that are not repeats already
+    uint64_t shadow_inert = 0, box_inert = 0, sphere_inert = 0, tri_inert = 0, rect_inert = 0;
     void add(const Counters& o)
     {
         rays_path += o.rays_path; rays_shadow += o.rays_shadow; rays_redundant += o.rays_redundant;
         box_tests += o.box_tests; sphere_tests += o.sphere_tests; tri_tests += o.tri_tests;
         rect_tests += o.rect_tests; hit_nodes += o.hit_nodes;
         box_repeats += o.box_repeats; sphere_repeats += o.sphere_repeats; tri_repeats += o.tri_repeats; rect_repeats += o.rect_repeats;
+        shadow_inert += o.shadow_inert; box_inert += o.box_inert; sphere_inert += o.sphere_inert; tri_inert += o.tri_inert; rect_inert += o.rect_inert;
     }
 };
 thread_local Counters* t_cnt = nullptr;
 thread_local int t_repeat = 0;   // > 0 while the traversal only repeats tests (see Counters)
+thread_local int t_inert = 0;    // > 0 during the traversal of a shadow ray that cannot matter
+thread_local bool t_ordinary = false;   // every material and light value of the scene is of ordinary size (see PointLight)
 Counters g_sink;
 inline Counters& C() { return t_cnt ? *t_cnt : g_sink; }
 
@@ -286,6 +292,7 @@ struct AABB {
     {
         C().box_tests++;
         if (t_repeat) C().box_repeats++;
+        else if (t_inert) C().box_inert++;
         float t1 = (min.X - ray.origin.X) * ray.dirFrac.X;
         float t2 = (max.X - ray.origin.X) * ray.dirFrac.X;
         float t3 = (min.Y - ray.origin.Y) * ray.dirFrac.Y;
@@ -342,6 +349,7 @@ struct Sphere : Surface {
     {
         C().sphere_tests++;
         if (t_repeat) C().sphere_repeats++;
+        else if (t_inert) C().sphere_inert++;
         Vec distance = ray.origin - origin;
         float a = DistanceSquared(ray.direction, V(0, 0, 0));
         float half_b = Dot(distance, ray.direction);
@@ -376,6 +384,7 @@ struct RectAxis : Surface {
     {
         C().rect_tests++;
         if (t_repeat) C().rect_repeats++;
+        else if (t_inert) C().rect_inert++;
         float t = (-k - ray.origin.Z / ray.direction.Z);
         if (t < t_min || t > t_max) return false;
         float x = ray.origin.X + (t * ray.direction.X);
@@ -408,6 +417,7 @@ struct Tri : Surface {
     {
         C().tri_tests++;
         if (t_repeat) C().tri_repeats++;
+        else if (t_inert) C().tri_inert++;
         Vec pVec = Cross(ray.direction, AC);  // a racy instance field in the reference (:599,679); local here
         float discriminant = Dot(AB, pVec);
         if ((double)discriminant < 1e-8 && !flipNormal) return false;
@@ -634,8 +644,27 @@ struct PointLight : Light {
         // Shadow ray.  It is a closest-hit query that overwrites `record`, so from here on
         // record.point / record.t / record.hitMat belong to the occluder if there is one.
         C().rays_shadow++;
-        if (world->hit(CustomRay(record.point, directionToLight + ReturnRandomRangedVector(AuxWord(key, 1u + lightIndex), 0.95f)),
-                       0.001f, std::numeric_limits<float>::infinity(), record))
+        // Bookkeeping only (the ray is traced all the same): with the light behind the surface (NdotL = 0) SmithL, and
+        // with it geoShadow, the diffuse term and ggx are 0 -- provided every other factor is finite --, so lightLevel is
+        // formerLightLevel and the specular term is 0 whatever the shadow ray meets.  An implementation may leave such a
+        // ray out; its tests are counted apart so that the counts of one that does can be checked.  "Finite" is made
+        // certain by: roughSqr in [2^-20, 2] (D and vis stay bounded), |directionToLight + Normalize(-direction)|^2 in
+        // [2^-60, 8] (a finite half vector), hit point and normal of ordinary size, and ordinary material / light values
+        // throughout the scene (t_ordinary).
+        bool inert = false;
+        if (t_ordinary) {
+            const float big = 0x1p40f;
+            const float s2 = Magnitude(directionToLight + Normalize(-ray.direction));   // the squared length
+            const Vec P = record.point, N = record.normal;
+            const bool tame = std::fabs(P.X) <= big && std::fabs(P.Y) <= big && std::fabs(P.Z) <= big &&
+                              std::fabs(N.X) <= big && std::fabs(N.Y) <= big && std::fabs(N.Z) <= big;
+            inert = NdotL == 0.0f && roughSqr >= 0x1p-20f && roughSqr <= 2.0f && s2 >= 0x1p-60f && s2 <= 8.0f && tame;
+        }
+        if (inert) { C().shadow_inert++; t_inert++; }
+        const bool shadowRayHit = world->hit(CustomRay(record.point, directionToLight + ReturnRandomRangedVector(AuxWord(key, 1u + lightIndex), 0.95f)),
+                                             0.001f, std::numeric_limits<float>::infinity(), record);
+        if (inert) t_inert--;
+        if (shadowRayHit)
             if (Magnitude(CustomRay(record.point, directionToLight).getPos(record.t) - record.point) < Magnitude(position - record.point)) {
                 lightLevel = formerLightLevel;
                 ggx = 0;
@@ -849,6 +878,19 @@ const Surface* pickWorld(const orc_scene* s, int kind)
 
 Vec A3(const float* p) { return V(p[0], p[1], p[2]); }
 
+// Albedo and metalness of every material, position, colour and brightness of every light at most 2^40 in size (and
+// not NaN): what PointLight.calculateLight's note on shadow rays that cannot matter asks of the scene.
+bool sceneIsOrdinary(const orc_scene* s)
+{
+    const float big = 0x1p40f;
+    auto ok = [&](float v) { return std::fabs(v) <= big; };
+    for (const Material& m : s->materials)
+        if (!(ok(m.albedo.X) && ok(m.albedo.Y) && ok(m.albedo.Z) && ok(m.metalness))) return false;
+    for (const auto& l : s->lights.lightArray)
+        if (!(ok(l->position.X) && ok(l->position.Y) && ok(l->position.Z) && ok(l->lightColor.X) && ok(l->lightColor.Y) && ok(l->lightColor.Z) && ok(l->brightness))) return false;
+    return true;
+}
+
 // Game1.cs:264-317, one band of scanlines.
 void renderBlock(const orc_scene* s, const Surface* world, const orc_camera* cam, const orc_params* p, int yStart, int yEnd,
                  int xStart, int xEnd, uint32_t* out, uint32_t* nodesPerPixel, Counters* counters, int sampleFirst, int sampleCount)
@@ -856,6 +898,7 @@ void renderBlock(const orc_scene* s, const Surface* world, const orc_camera* cam
     // sampleFirst / sampleCount: renderBlock runs all samples (0, samples); renderBlockFull (Game1.cs:320-374) is the
     // same loop body run for ONE sample -- still divided by `samples` (:352) -- into a buffer of its own.
     t_cnt = counters;
+    t_ordinary = sceneIsOrdinary(s);
     const Vec camPos = A3(cam->position), llc = A3(cam->lower_left), horiz = A3(cam->horizontal), vert = A3(cam->vertical);
     const int samples = p->samples;
     for (int y = yStart; y < yEnd; y++) {
@@ -1120,6 +1163,8 @@ static int RenderSamples(const orc_scene* s, const orc_camera* cam, const orc_pa
         stats->rect_tests = total.rect_tests; stats->hit_nodes = total.hit_nodes;
         stats->box_repeats = total.box_repeats; stats->sphere_repeats = total.sphere_repeats;
         stats->tri_repeats = total.tri_repeats; stats->rect_repeats = total.rect_repeats;
+        stats->shadow_inert = total.shadow_inert; stats->box_inert = total.box_inert; stats->sphere_inert = total.sphere_inert;
+        stats->tri_inert = total.tri_inert; stats->rect_inert = total.rect_inert;
         stats->seconds = std::chrono::duration<double>(t1 - t0).count();
         stats->threads_used = n;
     }
@@ -1152,6 +1197,7 @@ int orc_render_mix_buffers(const orc_scene* s, const orc_camera* cam, const orc_
         total.box_tests += one.box_tests; total.sphere_tests += one.sphere_tests; total.tri_tests += one.tri_tests;
         total.rect_tests += one.rect_tests; total.hit_nodes += one.hit_nodes; total.seconds += one.seconds; total.threads_used = one.threads_used;
         total.box_repeats += one.box_repeats; total.sphere_repeats += one.sphere_repeats; total.tri_repeats += one.tri_repeats; total.rect_repeats += one.rect_repeats;
+        total.shadow_inert += one.shadow_inert; total.box_inert += one.box_inert; total.sphere_inert += one.sphere_inert; total.tri_inert += one.tri_inert; total.rect_inert += one.rect_inert;
         for (size_t i = 0; i < n; i++) {
             // Color.ToVector3(): (R / 255f, G / 255f, B / 255f)
             Vec tempBuffCol = V((float)(out[i] & 255u) / 255.0f, (float)((out[i] >> 8) & 255u) / 255.0f, (float)((out[i] >> 16) & 255u) / 255.0f);

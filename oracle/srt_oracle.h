@@ -58,6 +58,11 @@ typedef struct {
        per-light re-intersection (RaytracingClasses.cs:211) and the second test of a single-surface leaf (:362-365).
        An implementation that reuses those answers performs exactly (tests - repeats) tests. */
     uint64_t box_repeats, sphere_repeats, tri_repeats, rect_repeats;
+    /* Shadow rays that cannot change what PointLight.calculateLight returns (light behind the surface, all factors
+       finite; the conditions are spelled out there), and the part of the four *_tests that belongs to their traversals
+       and is not counted under *_repeats already.  The oracle traces them all the same; an implementation that leaves
+       them out performs (tests - repeats - inert) tests. */
+    uint64_t shadow_inert, box_inert, sphere_inert, tri_inert, rect_inert;
 } orc_stats;
 
 typedef struct orc_scene orc_scene;

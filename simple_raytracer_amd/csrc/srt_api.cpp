@@ -134,7 +134,7 @@ struct srt_ctx {
 
 namespace {
 
-constexpr int kStatsWords = 48;   // counters a trace kernel adds to (srt_launch.h)
+constexpr int kStatsWords = 56;   // counters a trace kernel adds to (srt_launch.h)
 thread_local std::string g_create_error;
 
 int fail(srt_ctx* c, int code, const std::string& msg)
@@ -195,6 +195,7 @@ void zero_counts(srt_stats& s)
     s.box_tests = s.sphere_tests = s.tri_tests = s.rect_tests = 0;
     s.trace_sections = s.trace_lanes = s.light_sections = s.light_lanes = 0;
     for (int i = 0; i < 16; i++) s.section_cycles[i] = s.section_lane_cycles[i] = 0;
+    s.shadow_unasked = 0;
     s.kernel_ms = 0.0;
 }
 
@@ -226,6 +227,7 @@ int collect_stats(srt_ctx* c)
         p.box_tests = s[3]; p.sphere_tests = s[4]; p.tri_tests = s[5]; p.rect_tests = s[6];
         p.trace_sections = s[7]; p.trace_lanes = s[8]; p.light_sections = s[9]; p.light_lanes = s[10];
         for (int i = 0; i < 16; i++) { p.section_cycles[i] = s[16 + i]; p.section_lane_cycles[i] = s[32 + i]; }
+        p.shadow_unasked = s[48];
         if (d.walk_tune == WALK_TUNE_CALIBRATE && s[13] >= kWalkTuneEnoughTicks && s[15] >= kWalkTuneEnoughTicks)
             d.walk_tune = walk_tune_prefers_short((double)s[12], (double)s[13], (double)s[14], (double)s[15]) ? WALK_TUNE_SHORT : WALK_TUNE_LONG;
         p.kernel_ms = ms;
@@ -240,6 +242,7 @@ int collect_stats(srt_ctx* c)
         t.box_tests += p.box_tests; t.sphere_tests += p.sphere_tests; t.tri_tests += p.tri_tests; t.rect_tests += p.rect_tests;
         t.trace_sections += p.trace_sections; t.trace_lanes += p.trace_lanes; t.light_sections += p.light_sections; t.light_lanes += p.light_lanes;
         for (int i = 0; i < 16; i++) { t.section_cycles[i] += p.section_cycles[i]; t.section_lane_cycles[i] += p.section_lane_cycles[i]; }
+        t.shadow_unasked += p.shadow_unasked;
         if (p.kernel_ms > t.kernel_ms) t.kernel_ms = p.kernel_ms;
     }
     c->stats.walk_tune = (uint32_t)c->dev[0].walk_tune;

@@ -235,6 +235,10 @@ struct SceneView {
     // largest origin distance L0 the boxes were padded for, and the padding per unit of distance beyond it.
     f3 far_center;
     float far_radius, far_L0, far_slope;
+    // Non-zero: the kernel of this scene leaves out the shadow rays that cannot change their light's contribution
+    // (shadow_ray_matters); the host sets it for scenes whose queries are stack traversals and whose material and
+    // light values are all of ordinary size.
+    uint32_t inert_lights;
 };
 
 struct Material { f3 albedo; float metalness; float smoothness; f3 emission; };
@@ -752,6 +756,37 @@ SRT_HD f3 point_light(const Light& L, f3 P, f3 N, f3 dir, const Material& m, f3 
     const float inv_pi = 1.0f / pi;  // Vector3 / float multiplies by the reciprocal
     f3 spec = scale3(scale3(scale3(lerp, inv_pi), ggx), att);
     return add3(level, spec);
+}
+
+// Whether the shadow ray of light L at the hit (P, N) of a ray with direction `dir` can influence what
+// PointLight.calculateLight returns.  It cannot when the light is behind the surface and everything involved is of
+// ordinary size: with NdotL = 0 (RaytracingClasses.cs:113) SmithL = 2 / (1 + sqrt(1 + r2 / 0)) = 0, so the diffuse term
+// (:160-161) is lightAlbedo (1 - metalness) * (0 * NdotV) * 0 * brightness * attenuation = 0 and lightLevel is
+// formerLightLevel whether or not line :178 resets it; and ggx = 0 * D * F * vis (:155) is 0 whether or not line :179
+// resets it, so the specular term (:185) is Lerp(..., metalness of whatever the shadow ray hit) / pi * 0 * attenuation
+// = 0 for any occluder.  That needs every other factor to be finite, which the conditions below guarantee:
+//   r2 in [2^-20, 2]        D = r2 / (pi denom^2) with denom = NdotH^2 (r2 - 1) + 1 >= 2^-24 (r2 - 1 > -1 in float), and
+//                           vis = 1 / k * 1 / (NdotV (1 - k) + k) with k = r2 / 2 in (0, 1], both factors <= 2^21;
+//   |to_light + view|^2 in [2^-60, 8]   the half vector is finite (and so are to_light and view), so with a finite N the
+//                           clamped dot products NdotV, NdotH, LdotH are numbers in [0, 1] and F is in [0.5, 1];
+//   P and N of ordinary size (the attenuation is a number in [0, 1]); albedo, metalness, light colour, brightness and
+//   position of ordinary size for every material and light of the scene (sc.inert_lights, checked by the host).
+// formerLightLevel is a sum that started at +0, so it is never -0 and adding a zero of either sign returns it unchanged:
+// the call returns formerLightLevel bit for bit, with or without the shadow ray.  NdotL is computed exactly as
+// point_light() computes it.
+SRT_HD bool shadow_ray_matters(const SceneView& sc, const Light& L, f3 P, f3 N, f3 dir, float smoothness)
+{
+    if (sc.inert_lights == 0u) return true;
+    const float big = 0x1p40f;
+    const float roughness = 1.0f - smoothness;
+    const float r2 = roughness * roughness;
+    const f3 to_light = normalize3(sub3(L.position, P));
+    const f3 view = normalize3(neg3(dir));
+    const float NdotL = clampf(dot3(N, to_light), 0.0f, 1.0f);
+    const float s2 = lensq3(add3(to_light, view));
+    const bool tame = (fabsf(P.x) <= big) & (fabsf(P.y) <= big) & (fabsf(P.z) <= big) & (fabsf(N.x) <= big) & (fabsf(N.y) <= big) & (fabsf(N.z) <= big);
+    const bool inert = (NdotL == 0.0f) & (r2 >= 0x1p-20f) & (r2 <= 2.0f) & (s2 >= 0x1p-60f) & (s2 <= 8.0f) & tame;   // all false for NaN
+    return !inert;
 }
 
 // ------------------------------------------------------------------------------------------

@@ -128,6 +128,7 @@ struct TreeFork {
 };
 constexpr uint32_t kMaxStalledTrips = 4096u;   // trips in a row with only waiting lanes before a wavefront gives up (never reached unless a colour is lost)
 constexpr int kStatsAlarm = 11;                // stats word that counts wavefronts that gave up
+constexpr int kStatsUnasked = 48;              // stats word that counts the shadow queries answered without a traversal
 constexpr int kStatsTune = 12;                 // stats words 12-15: traversals finished / wall-clock ticks under quantum preset 0, then 1
 constexpr int kForkMinDepth = 2;       // only subtrees that can still grow (remaining depth >= this)
 constexpr int kSteadyForkDepth = 5;    // mesh kernel, while new items are left: only subtrees with at least this much depth left
@@ -593,6 +594,19 @@ __global__ void __launch_bounds__(kBlock, SRT_WAVES_PER_SIMD_MESH) mesh_trace_ke
     };
     if (calibrating) { settle(false); tune_start = wall_clock64(); }
 
+    // the shadow query of light `light`; a ray that cannot matter is answered on the spot ("hit nothing")
+    uint32_t unasked = 0u;     // counting builds: shadow queries answered that way
+    auto begin_shadow = [&](const uint32_t aux[4]) {
+        f3 o, d;
+        lane_shadow_query(ln, sc, light, aux, unit, o, d);
+        tr.d = d;
+        if (lane_shadow_matters(ln, sc, light)) tr.cur = TRAV_NEW;
+        else {
+            tr.cur = TRAV_NONE;
+            tr.best.t = INFINITY; tr.best.prim = NO_PRIM; tr.best.u = tr.best.v = 0.0f; tr.best.order = 0u;
+            if (COUNT) unasked++;
+        }
+    };
     // the lane's next state after a per-lane function returned LANE_*; `ret` is the sample's colour for LANE_IDLE;
     // up: the function was lane_return (frames may have gone, a later child may have started), else a frame may have
     // been pushed
@@ -620,9 +634,8 @@ __global__ void __launch_bounds__(kBlock, SRT_WAVES_PER_SIMD_MESH) mesh_trace_ke
             light = 0u;
             uint32_t aux[4];
             rng_call(ln.key, CALL_AUX, aux);
-            f3 o, d;
-            lane_shadow_query(ln, sc, 0u, aux, unit, o, d);
-            tr.d = d; tr.cur = TRAV_NEW; phase = MESH_SHADOW;
+            begin_shadow(aux);
+            phase = MESH_SHADOW;
         }
     };
 
@@ -741,9 +754,7 @@ __global__ void __launch_bounds__(kBlock, SRT_WAVES_PER_SIMD_MESH) mesh_trace_ke
                 uint32_t aux[4];
                 rng_call(ln.key, CALL_AUX, aux);
                 if (light < sc.n_lights) {
-                    f3 o, d;
-                    lane_shadow_query(ln, sc, light, aux, unit, o, d);
-                    tr.d = d; tr.cur = TRAV_NEW;
+                    begin_shadow(aux);
                 } else {
                     f3 ret;
                     int p = lane_shade(ln, ln.former, ret, sc, ra, frames, aux, unit);
@@ -772,6 +783,7 @@ __global__ void __launch_bounds__(kBlock, SRT_WAVES_PER_SIMD_MESH) mesh_trace_ke
             if (lane == 0u) atomicAdd(&stats[32 + i], lanes);
         }
         unsigned long long c0 = wave_sum(cnt.box_tests), c1 = wave_sum(cnt.sphere_tests), c2 = wave_sum(cnt.tri_tests), c3 = wave_sum(cnt.rect_tests);
+        const unsigned long long c4 = wave_sum(unasked);   // shadow queries answered without a traversal
         if (lane == 0u) {
             atomicAdd(&stats[3], c0);
             atomicAdd(&stats[4], c1);
@@ -780,6 +792,7 @@ __global__ void __launch_bounds__(kBlock, SRT_WAVES_PER_SIMD_MESH) mesh_trace_ke
             for (int i = 0; i < 4; i++) atomicAdd(&stats[7 + i], (unsigned long long)sect[i]);
             for (int i = 0; i < PROF_WAIT_RETURN; i++) atomicAdd(&stats[16 + i], prof.cyc[i]);
             atomicAdd(&stats[16 + 15], (unsigned long long)handed);   // a count, not cycles
+            atomicAdd(&stats[kStatsUnasked], c4);
         }
     }
 }

@@ -361,6 +361,12 @@ SRT_HD void lane_shadow_query(const Lane& ln, const SceneView& sc, uint32_t li, 
     o = ln.P;
     d = shadow_direction(L, ln.P, light_word(ln.key, aux, li), unit);
 }
+// Whether that query has to be made at all (see shadow_ray_matters); when not, the light is evaluated as if the ray had
+// hit nothing.
+SRT_HD bool lane_shadow_matters(const Lane& ln, const SceneView& sc, uint32_t li)
+{
+    return shadow_ray_matters(sc, load_light(sc, li), ln.P, ln.N, ln.qd, sc.materials[2 * ln.mat + 1].x);
+}
 // ... and its contribution once the shadow ray (o, d) came back: formerLightLevel += calculateLight(formerLightLevel, ...)
 SRT_HD void lane_on_shadow(Lane& ln, const Hit& h, f3 o, f3 d, const SceneView& sc, uint32_t li)
 {

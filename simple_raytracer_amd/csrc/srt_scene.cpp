@@ -855,6 +855,18 @@ int flatten_scene(const HostScene& in, int world_kind, FlatScene& out, std::stri
         out.list_count = (uint32_t)total;
         out.has_bvh = 0;
     }
+    // Scenes whose queries are stack traversals leave out the shadow rays that cannot matter (shadow_ray_matters in
+    // srt_core.h), provided every material and light value is of ordinary size.
+    {
+        const float big = 0x1p40f;
+        bool ordinary = true;
+        for (const srt_material& m : in.materials)
+            ordinary = ordinary && std::fabs(m.albedo[0]) <= big && std::fabs(m.albedo[1]) <= big && std::fabs(m.albedo[2]) <= big && std::fabs(m.metalness) <= big;   // false for NaN
+        for (const srt_point_light& l : in.lights)
+            ordinary = ordinary && std::fabs(l.position[0]) <= big && std::fabs(l.position[1]) <= big && std::fabs(l.position[2]) <= big &&
+                       std::fabs(l.color[0]) <= big && std::fabs(l.color[1]) <= big && std::fabs(l.color[2]) <= big && std::fabs(l.brightness) <= big;
+        out.inert_lights = (ordinary && out.has_bvh != 0u && out.n_tiny == 0u) ? 1u : 0u;
+    }
     // never hand the device an empty allocation
     q4 zero = mkq(0, 0, 0, 0);
     if (out.nodes.empty()) out.nodes.assign(2, zero);

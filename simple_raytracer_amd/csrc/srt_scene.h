@@ -41,6 +41,7 @@ struct FlatScene {
     // far-origin guard of the library's own tree (SceneView::far_*); far_L0 = infinity when there is no such tree
     float far_center[3] = {0.0f, 0.0f, 0.0f};
     float far_radius = 0.0f, far_L0 = INFINITY, far_slope = 0.0f;
+    uint32_t inert_lights = 0;   // SceneView::inert_lights
 
     // The view the kernels take, over device (or, for the CPU harness, host) copies of the arrays.
     SceneView view(const q4* d_nodes, const q4* d_prims, const q4* d_normals, const q4* d_materials, const q4* d_lights, const q4* d_tiny) const
@@ -53,6 +54,7 @@ struct FlatScene {
         v.hit_prims = d_prims;
         v.far_center = mk3(far_center[0], far_center[1], far_center[2]);
         v.far_radius = far_radius; v.far_L0 = far_L0; v.far_slope = far_slope;
+        v.inert_lights = inert_lights;
         return v;
     }
 };

@@ -191,6 +191,7 @@ class Renderer:
         out = {k: getattr(st, k) for k, _ in N.Stats._fields_ if k != "reserved"}
         out["section_cycles"] = list(st.section_cycles)
         out["section_lane_cycles"] = list(st.section_lane_cycles)
+        out["shadow_unasked"] = int(st.shadow_unasked)
         return out
 
     def stats(self):

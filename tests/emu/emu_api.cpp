@@ -51,7 +51,7 @@ Hit query(const SceneView& sc, f3 o, f3 d, float t_min, uint32_t* stack, Counter
     return tr.best;
 }
 
-struct Totals { uint64_t v[7] = {0, 0, 0, 0, 0, 0, 0}; };
+struct Totals { uint64_t v[8] = {0, 0, 0, 0, 0, 0, 0, 0}; };   // rays, hit nodes, tests; 7: shadow queries left out
 
 // Items [i0, i1) of one pass, one lane at a time: the same per-lane functions the kernel calls, without the
 // wavefront scheduling around them (which does not influence results).
@@ -60,6 +60,7 @@ void run_items(const SceneView& sc, const RenderArgs& ra, uint32_t i0, uint32_t 
 {
     std::vector<uint32_t> stack(STACK_DEPTH);
     Counters cnt{0, 0, 0, 0};
+    uint64_t unasked = 0;
     float unit[UNIT_TABLE];
     fill_unit_table(unit);
     for (uint32_t item = i0; item < i1; item++) {
@@ -83,7 +84,10 @@ void run_items(const SceneView& sc, const RenderArgs& ra, uint32_t i0, uint32_t 
                 for (uint32_t li = 0; li < sc.n_lights; li++) {
                     f3 o, d;
                     lane_shadow_query(ln, sc, li, aux, unit, o, d);
-                    Hit h = query<EXACT>(sc, o, d, 0.001f, stack.data(), cnt);
+                    Hit h;
+                    h.t = INFINITY; h.prim = NO_PRIM; h.u = h.v = 0.0f; h.order = 0u;
+                    if (lane_shadow_matters(ln, sc, li)) h = query<EXACT>(sc, o, d, 0.001f, stack.data(), cnt);
+                    else unasked++;
                     lane_on_shadow(ln, h, o, d, sc, li);
                 }
                 phase = lane_shade(ln, ln.former, ret, sc, ra, frames, aux, unit);
@@ -93,6 +97,7 @@ void run_items(const SceneView& sc, const RenderArgs& ra, uint32_t i0, uint32_t 
         tot->v[0] += ln.rays_path; tot->v[1] += ln.rays_shadow; tot->v[2] += ln.hit_nodes;
     }
     tot->v[3] += cnt.box_tests; tot->v[4] += cnt.sphere_tests; tot->v[5] += cnt.tri_tests; tot->v[6] += cnt.rect_tests;
+    tot->v[7] += unasked;
 }
 
 }  // namespace
@@ -235,10 +240,11 @@ static int render_passes(srt_ctx* c, const srt_render_params* p, uint32_t* out, 
         if (mix_buffers > 0)
             for (size_t i = 0; i < buffer.size(); i++) frame[i] = mix_colors(s0 == 0 ? 0u : frame[i], buffer[i]);   // mix_kernel
     }
-    uint64_t s[7] = {0, 0, 0, 0, 0, 0, 0};
-    for (auto& t : tot) for (int i = 0; i < 7; i++) s[i] += t.v[i];
+    uint64_t s[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    for (auto& t : tot) for (int i = 0; i < 8; i++) s[i] += t.v[i];
     c->stats.rays_path = s[0]; c->stats.rays_shadow = s[1]; c->stats.hit_nodes = s[2];
     c->stats.box_tests = s[3]; c->stats.sphere_tests = s[4]; c->stats.tri_tests = s[5]; c->stats.rect_tests = s[6];
+    c->stats.shadow_unasked = s[7];
     return SRT_OK;
 }
 
@@ -264,7 +270,7 @@ struct EmuDevices {
         int rc = render_passes(c, &plan.part[k], out, 0);
         total.rays_path += c->stats.rays_path; total.rays_shadow += c->stats.rays_shadow; total.hit_nodes += c->stats.hit_nodes;
         total.box_tests += c->stats.box_tests; total.sphere_tests += c->stats.sphere_tests; total.tri_tests += c->stats.tri_tests;
-        total.rect_tests += c->stats.rect_tests;
+        total.rect_tests += c->stats.rect_tests; total.shadow_unasked += c->stats.shadow_unasked;
         return rc;
     }
     int gather(const MultiPlan& plan)

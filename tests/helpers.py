@@ -186,6 +186,30 @@ def mesh_spec(kind="sphere", n=16, with_spheres=True, with_rect=False):
     return s
 
 
+def inert_light_spec(kind):
+    """mesh_spec() bent towards the edges of the rule for shadow rays that cannot matter (a light behind the surface):
+    "plain" keeps it as it is; "mirror" makes every material perfectly smooth (roughness 0, where the rule does not
+    apply); "rough" uses the smoothness values at and next to the ends of [0, 1], to which the Material constructor clamps;
+    "huge-brightness", "huge-light" and "nan-metal" carry values for which the scene as a whole must keep all its shadow
+    rays (albedo and metalness are clamped to [0, 1] by the constructor, RaytracingClasses.cs:221-262, but a NaN passes)."""
+    s = mesh_spec()
+    z = (0, 0, 0)
+    if kind == "mirror":
+        s.materials = [(a, m, 1.0, e) for a, m, _, e in s.materials]
+    elif kind == "rough":
+        s.materials = [((1.0, 0.5, 0.5), 0.0, -0.5, z), ((0.6, 0.7, 0.9), 0.4, 2.3, z), ((0.5, 0.45, 0.3), 0.0, 1.0 - 2.0 ** -11, z),
+                       ((0.9, 0.9, 0.9), 1.0, 1.0 + 2.0 ** -9, z), (z, 0.0, 0.0, (4.0, 3.0, 1.0))]
+    elif kind == "huge-brightness":
+        s.lights[0] = ((4.0, -3.0, 1.0), 3.0e12, None)
+    elif kind == "huge-light":
+        s.lights[1] = ((-3.0e13, -2.0, -2.0), 2.0, (1.2, 0.4, 0.4))
+    elif kind == "nan-metal":
+        s.materials[1] = ((0.6, 0.7, 0.9), float("nan"), 0.7, z)
+    elif kind != "plain":
+        raise ValueError(kind)
+    return s
+
+
 def stray_spec(kind):
     """300 random triangles and a sphere, plus surfaces whose coordinates leave the range in which a surface test
     stays finite: NaN or infinite vertices, or a triangle 1e20 / 3e38 across.  The reference's tests then report

@@ -381,4 +381,30 @@ def test_gpu_reference_tree_counts_are_the_oracles(gpu, oracle, name):
     st, ost, mine, theirs, lsb, _ = reference_tree.run(gpu, oracle, name)
     assert lsb <= 1
     assert mine == theirs, (mine, theirs)
-    reference_tree.check_counts(st, ost)
+    unasked = reference_tree.check_counts(st, ost)
+    assert (unasked > 0) == (name in reference_tree.STACK_WALKED), (name, unasked)   # the scenes that leave shadow rays out did so
+
+
+@pytest.mark.parametrize("world_kind", ["bvhnode", "surfacelist"])
+@pytest.mark.parametrize("kind", ("plain", "mirror", "rough", "huge-brightness", "huge-light", "nan-metal"))
+def test_gpu_shadow_rays_that_cannot_matter_are_the_oracles(gpu, oracle, kind, world_kind):
+    """Stack-walked scenes leave out the shadow ray of a light behind the surface (its contribution is exactly nothing
+    whatever the ray meets, RaytracingClasses.cs:113-185 with NdotL = 0): the picture stays the oracle's, the rays left out
+    are exactly the ones the oracle's restatement of the rule marks, and what lies outside the rule's conditions (no
+    roughness, values that are not of ordinary size) keeps its shadow rays."""
+    spec = helpers.inert_light_spec(kind)
+    w, h = 96, 54
+    world, lights, cam = spec.host(w, h)
+    gpu.set_scene(world, lights, cam, world_kind=srt.WORLD_BVHNODE if world_kind == "bvhnode" else srt.WORLD_SURFACELIST)
+    img = gpu.render(w, h, samples=2, max_depth=4, seed=9, counted=True)
+    st = gpu.stats()
+    ref, ost = spec.oracle_scene().render(spec.oracle_camera(w, h), w, h, samples=2, max_depth=4, seed=9,
+                                          world_kind=oracle.WORLD_BVHNODE if world_kind == "bvhnode" else oracle.WORLD_SURFACELIST)
+    lsb, _ = helpers.max_lsb_diff(img, ref)
+    assert lsb <= 1
+    unasked = st["shadow_unasked"]
+    assert unasked == ost["shadow_inert"], (unasked, ost["shadow_inert"])
+    assert st["rays_shadow"] == ost["rays_shadow"]
+    assert (0 < unasked < st["rays_shadow"]) if kind in ("plain", "rough") else unasked == 0
+    plain = gpu.render(w, h, samples=2, max_depth=4, seed=9)     # the kernel without counters leaves out the same rays
+    assert np.array_equal(plain, img)

@@ -184,10 +184,42 @@ def test_reference_tree_is_the_oracles_tree(emu, oracle, name):
     st, ost, mine, theirs, lsb, osc = reference_tree.run(emu, oracle, name)
     assert lsb == 0
     assert mine == theirs, (mine, theirs)
-    reference_tree.check_counts(st, ost)
+    unasked = reference_tree.check_counts(st, ost)
+    assert (unasked > 0) == (name in reference_tree.STACK_WALKED), (name, unasked)   # the scenes that leave shadow rays out did so
     fn = emu._lib.srt_emu_leaf_order
     fn.restype = C.c_int64
     order = np.empty(st["n_prims"], np.uint32)
     n = fn(emu._ctx, order.ctypes.data_as(C.c_void_p), C.c_uint64(len(order)))
     assert n == st["n_prims"]
     assert list(order) == list(osc.bvh_leaf_order())
+
+
+INERT_KINDS = ("plain", "mirror", "rough", "huge-brightness", "huge-light", "nan-metal")
+
+
+@pytest.mark.parametrize("world_kind", ["bvhnode", "surfacelist"])
+@pytest.mark.parametrize("kind", INERT_KINDS)
+def test_shadow_rays_that_cannot_matter_are_the_oracles(emu, oracle, kind, world_kind):
+    """A light behind the surface adds exactly nothing whatever its shadow ray meets (RaytracingClasses.cs:113-185 with
+    NdotL = 0), so stack-walked scenes leave that ray out.  The picture must stay the oracle's bit for bit, the rays left
+    out must be exactly the ones the oracle's restatement of the rule marks, and scenes or materials outside the rule's
+    conditions (no roughness, values that are not of ordinary size) must keep their shadow rays."""
+    import helpers
+    spec = helpers.inert_light_spec(kind)
+    w, h = 56, 32
+    world, lights, cam = spec.host(w, h)
+    wk = srt.WORLD_BVHNODE if world_kind == "bvhnode" else srt.WORLD_SURFACELIST
+    emu.set_scene(world, lights, cam, world_kind=wk)
+    img = emu.render(w, h, samples=2, max_depth=4, seed=9, counted=True)
+    st = emu.stats()
+    ref, ost = spec.oracle_scene().render(spec.oracle_camera(w, h), w, h, samples=2, max_depth=4, seed=9,
+                                          world_kind=oracle.WORLD_BVHNODE if world_kind == "bvhnode" else oracle.WORLD_SURFACELIST)
+    lsb, _ = helpers.max_lsb_diff(img, ref)
+    assert lsb == 0
+    unasked = st["shadow_unasked"]
+    assert unasked == ost["shadow_inert"], (unasked, ost["shadow_inert"])
+    assert st["rays_shadow"] == ost["rays_shadow"]
+    if kind in ("plain", "rough"):
+        assert 0 < unasked < st["rays_shadow"]
+    else:
+        assert unasked == 0

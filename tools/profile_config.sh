@@ -7,6 +7,7 @@
 L=$1; shift
 export TMPDIR=/tmp
 R=${GRAFT_REPO_ROOT:-$(pwd)}
+rm -rf $R/gpurun_out/prof_${L}_trace $R/gpurun_out/prof_${L}_[1-5]   # results of earlier runs would be averaged in
 cd /tmp
 BENCH="python3 $R/bench.py --steps 3 --warmup 1 --no-cpu-baseline $*"
 timeout -s KILL 300 rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/prof_${L}_trace -- $BENCH > $R/gpurun_out/prof_${L}_trace.log 2>&1 || exit 1

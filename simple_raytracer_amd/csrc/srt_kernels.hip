@@ -594,18 +594,27 @@ __global__ void __launch_bounds__(kBlock, SRT_WAVES_PER_SIMD_MESH) mesh_trace_ke
     };
     if (calibrating) { settle(false); tune_start = wall_clock64(); }
 
-    // the shadow query of light `light`; a ray that cannot matter is answered on the spot ("hit nothing")
-    uint32_t unasked = 0u;     // counting builds: shadow queries answered that way
+    // The next shadow query of the node, starting with light `light`: lights whose ray cannot matter are accounted for
+    // on the spot.  Returns false when no light is left; the lane then stays in the "shadow answered" group without a
+    // query (asked = false), and that part shades the node.
+    uint32_t unasked = 0u;     // counting builds: shadow rays that were not traced
+    bool asked = false;        // MESH_SHADOW: tr holds the query of light `light`
     auto begin_shadow = [&](const uint32_t aux[4]) {
-        f3 o, d;
-        lane_shadow_query(ln, sc, light, aux, unit, o, d);
-        tr.d = d;
-        if (lane_shadow_matters(ln, sc, light)) tr.cur = TRAV_NEW;
-        else {
-            tr.cur = TRAV_NONE;
-            tr.best.t = INFINITY; tr.best.prim = NO_PRIM; tr.best.u = tr.best.v = 0.0f; tr.best.order = 0u;
+        while (light < sc.n_lights && !lane_shadow_matters(ln, sc, light)) {
+            lane_skip_light(ln);
+            light++;
             if (COUNT) unasked++;
         }
+        asked = light < sc.n_lights;
+        if (asked) {
+            f3 o, d;
+            lane_shadow_query(ln, sc, light, aux, unit, o, d);
+            tr.d = d;
+            tr.cur = TRAV_NEW;
+        } else {
+            tr.cur = TRAV_NONE;
+        }
+        return asked;
     };
     // the lane's next state after a per-lane function returned LANE_*; `ret` is the sample's colour for LANE_IDLE;
     // up: the function was lane_return (frames may have gone, a later child may have started), else a frame may have
@@ -749,12 +758,14 @@ __global__ void __launch_bounds__(kBlock, SRT_WAVES_PER_SIMD_MESH) mesh_trace_ke
             // ---- shadow queries that are answered: the light's contribution, then the next light or the shading
             if (COUNT) { sect[2]++; sect[3] += (uint32_t)n_shadow; }
             if (phase == MESH_SHADOW && !walking) {
-                lane_on_shadow(ln, tr.best, ln.P, tr.d, sc, light);
-                light++;
+                if (asked) {
+                    lane_on_shadow(ln, tr.best, ln.P, tr.d, sc, light);
+                    light++;
+                }
                 uint32_t aux[4];
                 rng_call(ln.key, CALL_AUX, aux);
-                if (light < sc.n_lights) {
-                    begin_shadow(aux);
+                if (begin_shadow(aux)) {
+                    // the next light's query is set up
                 } else {
                     f3 ret;
                     int p = lane_shade(ln, ln.former, ret, sc, ra, frames, aux, unit);

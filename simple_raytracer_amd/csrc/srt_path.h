@@ -367,6 +367,13 @@ SRT_HD bool lane_shadow_matters(const Lane& ln, const SceneView& sc, uint32_t li
 {
     return shadow_ray_matters(sc, load_light(sc, li), ln.P, ln.N, ln.qd, sc.materials[2 * ln.mat + 1].x);
 }
+// The contribution of a light whose shadow ray cannot matter: calculateLight returns formerLightLevel bit for bit
+// (shadow_ray_matters), so formerLightLevel += calculateLight(...) doubles it.  The ray still counts as a shadow ray.
+SRT_HD void lane_skip_light(Lane& ln)
+{
+    ln.rays_shadow++;
+    ln.former = add3(ln.former, ln.former);
+}
 // ... and its contribution once the shadow ray (o, d) came back: formerLightLevel += calculateLight(formerLightLevel, ...)
 SRT_HD void lane_on_shadow(Lane& ln, const Hit& h, f3 o, f3 d, const SceneView& sc, uint32_t li)
 {

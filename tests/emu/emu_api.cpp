@@ -82,12 +82,10 @@ void run_items(const SceneView& sc, const RenderArgs& ra, uint32_t i0, uint32_t 
                 uint32_t aux[4];
                 rng_call(ln.key, CALL_AUX, aux);
                 for (uint32_t li = 0; li < sc.n_lights; li++) {
+                    if (!lane_shadow_matters(ln, sc, li)) { lane_skip_light(ln); unasked++; continue; }
                     f3 o, d;
                     lane_shadow_query(ln, sc, li, aux, unit, o, d);
-                    Hit h;
-                    h.t = INFINITY; h.prim = NO_PRIM; h.u = h.v = 0.0f; h.order = 0u;
-                    if (lane_shadow_matters(ln, sc, li)) h = query<EXACT>(sc, o, d, 0.001f, stack.data(), cnt);
-                    else unasked++;
+                    Hit h = query<EXACT>(sc, o, d, 0.001f, stack.data(), cnt);
                     lane_on_shadow(ln, h, o, d, sc, li);
                 }
                 phase = lane_shade(ln, ln.former, ret, sc, ra, frames, aux, unit);

@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Benchmark of the trace loop on MI355X.
 
-    python bench.py --gpus N --steps K --warmup W [--config c2|c3|c4|c5]
+    python bench.py --gpus N --steps K --warmup W [--config c1|c2|c3|c4|c5]
 
 A step is one frame of the configuration, from the launch of its kernels to the frame's arrival in (pinned) host
 memory: trace + resolve kernels, with several GPUs the gather of the tile buffers and the assembly on the first one,
@@ -47,6 +47,8 @@ PEAK_HBM_GBS = 8000.0      # MI355X HBM3E peak
 
 # name -> (scene factory(width, height), world kind, width, height, spp per GPU, depth, description)
 CONFIGS = {
+    "c1": (lambda w, h: game1.default_scene(w, h), srt.WORLD_BVHNODE, 1280, 720, 500, 4,
+           "default Game1 scene at the reference's own settings (Game1.cs:41-43, 78-79), bvhnode world"),
     "c2": (lambda w, h: game1.default_scene(w, h), srt.WORLD_BVHNODE, 1920, 1080, 16, 8,
            "default Game1 scene (5 spheres, 2 point lights), bvhnode world"),
     "c3": (lambda w, h: scenes.teapot_scene(w, h, 2), srt.WORLD_SURFACELIST, 1920, 1080, 64, 4,
@@ -93,11 +95,12 @@ def cpu_baseline(name, world, lights, cam, width, height, spp, depth):
     a few columns x `threads` rows at the centre of the frame at 1 spp -- the reference's tree costs 10^4..10^5 box tests per ray."""
     from oracle import orc   # checker / baseline only
     threads = min(16, os.cpu_count() or 1)
-    if name == "c2":
+    if name in ("c1", "c2"):
         sc, ocam = orc.default_scene(), orc.default_camera(width, height)
-        _, st = sc.render(ocam, width, height, samples=spp, max_depth=depth, seed=1, window=(0, 0, width, height), threads=threads)
+        cpu_spp = min(spp, 64)   # a whole frame at up to 64 spp bounds the sample (the rate does not depend on the sample count)
+        _, st = sc.render(ocam, width, height, samples=cpu_spp, max_depth=depth, seed=1, window=(0, 0, width, height), threads=threads)
         sample = "one whole %dx%d %d-spp depth-%d frame (all rows, row bands over %d threads), %d rays in %.2f s" % (
-            width, height, spp, depth, threads, st["rays_path"], st["seconds"])
+            width, height, cpu_spp, depth, threads, st["rays_path"], st["seconds"])
     else:
         flat = world.flatten()
         mats = [orc.material(m.albedo, m.metalness, m.smoothness, m.emission) for m in flat["materials"]]
@@ -254,7 +257,7 @@ def main():
     if rank == 0:
         # Algorithmic work of ONE frame on this rank's devices, from the counting build of the same kernels.  The
         # big configurations count a 16-spp render of the same frame and scale by the sample ratio.
-        count_spp = spp if args.config == "c2" else min(spp, 16)
+        count_spp = spp if args.config == "c2" else min(spp, 16)   # the counting render of the other configurations is bounded; counts scale with spp
         pc = r.params(width, height, samples=count_spp, max_depth=depth, seed=1)
         if tf is not None:
             pc = r.params(width, height, samples=count_spp, max_depth=depth, seed=1, layout=srt.LAYOUT_TILES, tile_w=TILE, tile_h=TILE,
@@ -281,7 +284,7 @@ def main():
             fetch_kib, write_kib, where = MEASURED_TRAFFIC_KIB[args.config]
             traffic = int((2.0 * fetch_kib + write_kib) * 1024)
             traffic_source = "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command, 2*FETCH+WRITE (%s); constant, not re-measured in this run" % where
-        kernel = "trace_kernel" if args.config == "c2" else "mesh_trace_kernel"
+        kernel = "trace_kernel" if args.config in ("c1", "c2") else "mesh_trace_kernel"
         roofline.update({"traffic": traffic, "traffic_source": traffic_source, "kernel": kernel + " (+ resolve_kernel) of one frame",
                          "avg_launch_ms": round(avg_ms, 4),
                          "algorithmic_flops_per_launch": aflops, "algorithmic_bytes_per_launch": abytes,

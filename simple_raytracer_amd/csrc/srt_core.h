@@ -708,37 +708,23 @@ SRT_HD f3 shadow_direction(const Light& L, f3 P, uint32_t word, const float* uni
 // shadow ray came back.  `former` is formerLightLevel; shadow_hit/t_s/P_s/metal_s describe
 // what the shadow ray's closest-hit query left in `record` (the occluder), metal_s being the
 // primary material's metalness when the shadow ray hit nothing.
-// The factors of calculateLight that do not depend on the light: a kernel that evaluates the lights of a node one
-// after the other computes them once (the values are the same expressions on the same inputs either way).
-struct LitNode { float r2, k, NdotV, smithV, visV; f3 view; };
-SRT_HD LitNode lit_node(f3 N, f3 dir, const Material& m)
+SRT_HD f3 point_light(const Light& L, f3 P, f3 N, f3 dir, const Material& m, f3 former, bool shadow_hit, float t_s, f3 P_s, float metal_s)
 {
-    LitNode n;
     float roughness = 1.0f - m.smoothness;
-    n.r2 = roughness * roughness;
-    n.view = normalize3(neg3(dir));
-    n.NdotV = clampf(dot3(N, n.view), 0.0f, 1.0f);
-    float NdotV2 = n.NdotV * n.NdotV;
-    n.smithV = 2.0f / (1.0f + sqrt_rn(1.0f + n.r2 * (1.0f - NdotV2) / NdotV2));
-    n.k = n.r2 / 2.0f;
-    n.visV = 1.0f / (n.NdotV * (1.0f - n.k) + n.k);
-    return n;
-}
-SRT_HD f3 point_light(const Light& L, f3 P, f3 N, const LitNode& n, const Material& m, f3 former, bool shadow_hit, float t_s, f3 P_s, float metal_s)
-{
-    const float r2 = n.r2;
+    float r2 = roughness * roughness;
     float att = clampf(1.0f / distsq3(P, L.position), 0.0f, 1.0f);
     f3 to_light = normalize3(sub3(L.position, P));
-    f3 view = n.view;
+    f3 view = normalize3(neg3(dir));
     f3 half = normalize3(add3(to_light, view));
     float NdotL = clampf(dot3(N, to_light), 0.0f, 1.0f);
-    float NdotV = n.NdotV;
+    float NdotV = clampf(dot3(N, view), 0.0f, 1.0f);
     float LdotH = clampf(dot3(to_light, half), 0.0f, 1.0f);
     float NdotH = clampf(dot3(N, half), 0.0f, 1.0f);
 
-    float NdotL2 = NdotL * NdotL;
+    float NdotL2 = NdotL * NdotL, NdotV2 = NdotV * NdotV;
     float smithL = 2.0f / (1.0f + sqrt_rn(1.0f + r2 * (1.0f - NdotL2) / NdotL2));
-    float geo = smithL * n.smithV;
+    float smithV = 2.0f / (1.0f + sqrt_rn(1.0f + r2 * (1.0f - NdotV2) / NdotV2));
+    float geo = smithL * smithV;
     const float pi = 3.14159274f;  // (float)Math.PI
     float denom = NdotH * NdotH * (r2 - 1.0f) + 1.0f;
     float D = r2 / (pi * denom * denom);
@@ -746,8 +732,8 @@ SRT_HD f3 point_light(const Light& L, f3 P, f3 N, const LitNode& n, const Materi
     double x2 = x * x;
     float p5 = (float)(x2 * x2 * x);  // Math.Pow(1 - LdotH, 5)
     float F = 0.5f + (1.0f - 0.5f) * p5;
-    float k = n.k;
-    float vis = (1.0f / (NdotL * (1.0f - k) + k)) * n.visV;
+    float k = r2 / 2.0f;
+    float vis = (1.0f / (NdotL * (1.0f - k) + k)) * (1.0f / (NdotV * (1.0f - k) + k));
     float ggx = NdotL * D * F * vis;
     ggx *= (L.brightness / 2.0f);
 
@@ -770,10 +756,6 @@ SRT_HD f3 point_light(const Light& L, f3 P, f3 N, const LitNode& n, const Materi
     const float inv_pi = 1.0f / pi;  // Vector3 / float multiplies by the reciprocal
     f3 spec = scale3(scale3(scale3(lerp, inv_pi), ggx), att);
     return add3(level, spec);
-}
-SRT_HD f3 point_light(const Light& L, f3 P, f3 N, f3 dir, const Material& m, f3 former, bool shadow_hit, float t_s, f3 P_s, float metal_s)
-{
-    return point_light(L, P, N, lit_node(N, dir, m), m, former, shadow_hit, t_s, P_s, metal_s);
 }
 
 // Whether the shadow ray of light L at the hit (P, N) of a ray with direction `dir` can influence what

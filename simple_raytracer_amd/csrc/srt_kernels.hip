@@ -368,15 +368,13 @@ __global__ void __launch_bounds__(kBlock, SMALL ? SRT_WAVES_PER_SIMD : SRT_WAVES
                 uint32_t aux[4];
                 rng_call(ln.key, CALL_AUX, aux);
                 SRT_MARK(PROF_AUX);
-                const Material lit_mat = load_material(sc, ln.mat);
-                const LitNode lit = lit_node(ln.N, ln.qd, lit_mat);   // what the lights of the node have in common
                 for (uint32_t li = 0; li < sc.n_lights; li++) {
                     f3 o, d;
                     lane_shadow_query(ln, sc, li, aux, unit, o, d);
                     SRT_MARK(PROF_SHADOW_SETUP);
                     Hit h = closest_hit<EXACT, COUNT>(sc, o, d, 0.001f, cnt);
                     SRT_MARK(PROF_SHADOW_QUERY);
-                    lane_on_shadow(ln, h, o, d, sc, li, lit_mat, lit);
+                    lane_on_shadow(ln, h, o, d, sc, li);
                     SRT_MARK(PROF_LIGHT_EVAL);
                 }
                 f3 ret;

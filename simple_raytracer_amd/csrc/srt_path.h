@@ -375,9 +375,10 @@ SRT_HD void lane_skip_light(Lane& ln)
     ln.former = add3(ln.former, ln.former);
 }
 // ... and its contribution once the shadow ray (o, d) came back: formerLightLevel += calculateLight(formerLightLevel, ...)
-SRT_HD void lane_on_shadow(Lane& ln, const Hit& h, f3 o, f3 d, const SceneView& sc, uint32_t li, const Material& m, const LitNode& node)
+SRT_HD void lane_on_shadow(Lane& ln, const Hit& h, f3 o, f3 d, const SceneView& sc, uint32_t li)
 {
     ln.rays_shadow++;
+    Material m = load_material(sc, ln.mat);
     Light L = load_light(sc, li);
     bool sh = h.prim != NO_PRIM;
     f3 P_s = ln.P;
@@ -386,13 +387,8 @@ SRT_HD void lane_on_shadow(Lane& ln, const Hit& h, f3 o, f3 d, const SceneView& 
         P_s = ray_at(o, d, h.t);
         metal_s = sc.materials[2 * hit_material(sc, h)].w;
     }
-    f3 c = point_light(L, ln.P, ln.N, node, m, ln.former, sh, h.t, P_s, metal_s);
+    f3 c = point_light(L, ln.P, ln.N, ln.qd, m, ln.former, sh, h.t, P_s, metal_s);
     ln.former = add3(ln.former, c);
-}
-SRT_HD void lane_on_shadow(Lane& ln, const Hit& h, f3 o, f3 d, const SceneView& sc, uint32_t li)
-{
-    Material m = load_material(sc, ln.mat);
-    lane_on_shadow(ln, h, o, d, sc, li, m, lit_node(ln.N, ln.qd, m));
 }
 
 // Adds the samples of one pass to a pixel in sample order (Game1.cs:295: vectorRayColor += c / samples,

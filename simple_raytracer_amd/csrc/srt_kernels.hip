@@ -505,8 +505,9 @@ __global__ void __launch_bounds__(kBlock, SMALL ? SRT_WAVES_PER_SIMD : SRT_WAVES
 //   closest    its closest-hit query is answered: hit record, then the first shadow query, a child or a return;
 //   shadow     its shadow query is answered: light evaluation, then the next light, or the node's shading;
 //   up         it hands a value up the tree (RETURN) or is idle and wants a new item.
-// Each trip the wavefront runs a traversal quantum if at least kWalkVote lanes are walking, otherwise the part
-// that the most lanes are waiting for.  A quantum is kWalkRounds rounds of "descend at most kWalkSteps inner nodes,
+// Each trip the wavefront runs a traversal quantum if at least kWalkVote lanes are walking; with fewer it first serves
+// the largest of the other groups as long as one of them has kServeFirst lanes (10,000 spheres + mesh: 341 -> 310 ms
+// against "the part that the most lanes are waiting for"; the single meshes do not care), and walks otherwise.  A quantum is kWalkRounds rounds of "descend at most kWalkSteps inner nodes,
 // then test the leaf if one was reached".  Measured on a 983,040-triangle mesh (1080p, 64 spp; ms per frame): the
 // closest-hit / light sections of trace_kernel 56.1; quanta of 2 x 8 steps 58.2, 8 x 8 48.6, 32 x 8 44.7; unbounded
 // quanta (every traversal runs to its end once started) with 8 steps 43.3, 4 steps 40.8, 2 steps 43.1; and with
@@ -523,11 +524,12 @@ constexpr int kWalkVote = 16, kWalkRounds = 1 << 24, kWalkSteps = 2;
 // launches after a commit run both for 3 ms each (preset 0, then preset 1, once the launch is 5 ms old), every wavefront adds the traversals
 // it finished and the time it took to two pairs of counters, and whoever finds both pairs filled takes the faster preset;
 // the host reads the same counters when it collects the statistics and fixes the preset for later launches.
-constexpr int kShortVote = 56, kShortRounds = 4, kShortSteps = 4;
+constexpr int kShortVote = 56, kShortRounds = 6, kShortSteps = 4;
+constexpr int kServeFirst = 8;   // lanes in another group that make the wavefront serve that group before it walks (see the vote in the kernel)
 constexpr uint32_t kShortScatterSamples = 0xFFFFFFFFu;   // a short-quanta scene enumerates all samples of a pass in scattered order (8 of 16: 481 ms, all: 457 ms)
 constexpr unsigned long long kTuneWindowTicks = 300000ull;   // 3 ms of the 100 MHz wall clock per preset ...
 constexpr unsigned long long kTuneSkipTicks = 500000ull;     // ... after the first 5 ms of the launch: it starts with nothing but coherent primary rays
-struct WalkTune { int vote[2], rounds[2], steps[2]; int mode; };   // mode: WALK_TUNE_*; preset 0 / 1
+struct WalkTune { int vote[2], rounds[2], steps[2]; int mode; int serve; };   // mode: WALK_TUNE_*; preset 0 / 1; serve: see the vote   // mode: WALK_TUNE_*; preset 0 / 1
 
 template <bool EXACT, bool COUNT>
 __global__ void __launch_bounds__(kBlock, SRT_WAVES_PER_SIMD_MESH) mesh_trace_kernel(SceneView sc, RenderArgs ra, f3* __restrict__ samples,
@@ -695,7 +697,10 @@ __global__ void __launch_bounds__(kBlock, SRT_WAVES_PER_SIMD_MESH) mesh_trace_ke
         }
         stalled = 0u;
 
-        if (n_walk >= walk_vote || (n_walk >= n_closest && n_walk >= n_shadow && n_walk >= n_up)) {
+        // Short of walk_vote walking lanes, the other groups are served first while one of them has at least tune.serve
+        // lanes: their parts are short, and every lane they release joins the next quantum instead of sitting it out.
+        const bool serve = n_walk < walk_vote && (n_up >= tune.serve || n_closest >= tune.serve || n_shadow >= tune.serve);
+        if (!serve && n_walk > 0) {
             // ---- a quantum of traversal
             if (COUNT) { sect[0]++; sect[1] += (uint32_t)n_walk; }
             if (walking) {
@@ -922,6 +927,8 @@ hipError_t launch_trace(const SceneView& sc, const RenderArgs& ra_in, bool exact
     WalkTune tune;
     tune.vote[0] = walk_vote; tune.rounds[0] = walk_rounds; tune.steps[0] = walk_steps;
     tune.vote[1] = kShortVote; tune.rounds[1] = kShortRounds; tune.steps[1] = kShortSteps;
+    static const int serve = std::getenv("SRT_MESH_SERVE") ? std::atoi(std::getenv("SRT_MESH_SERVE")) : kServeFirst;
+    tune.serve = serve > 0 ? serve : 65;   // 65: never (experiments)
     tune.mode = walk_knobs ? WALK_TUNE_LONG : walk_tune;
     static const bool allow_fork = !std::getenv("SRT_NO_SUBTREE_SHARING");
     float4* timeline = reinterpret_cast<float4*>(d_timeline);

@@ -65,7 +65,7 @@ CONFIGS = {
 # config -> (FETCH_SIZE KiB, WRITE_SIZE KiB, the profile the numbers come from)
 MEASURED_TRAFFIC_KIB = {
     "c2": (3.869e5, 3.303e6, "profiles/r2b_c2_pmc_and_kernel_stats.txt"),   # trace_kernel<true,false,true>
-    "c3": (6.007e6, 7.198e6, "profiles/r2b_c3_pmc_and_kernel_stats.txt"),   # mesh_trace_kernel<false,false>
+    "c3": (5.921e6, 7.030e6, "profiles/r2b_c3_pmc_and_kernel_stats.txt"),   # mesh_trace_kernel<false,false>
 }
 
 # Algorithmic work per event: bytes fetched / FP32 operations (add, sub, mul, div, sqrt, min, max, compare = 1 each)

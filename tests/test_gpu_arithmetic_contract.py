@@ -1,6 +1,7 @@
 """The kernels promise IEEE float32 arithmetic in source order (no contraction, correctly rounded division and
 square root).  tests/gpu_probe/probe evaluates the building blocks of srt_core.h on the GPU and on the host from
-the same source and compares them bit for bit on a million random inputs each."""
+the same source and compares them bit for bit on a million random inputs each; tests/gpu_probe/exhaustive runs the
+device's short forms of reciprocal, 1 / sqrt and the Smith term on all 2^32 float bit patterns."""
 import os
 import re
 import subprocess
@@ -25,3 +26,17 @@ def test_device_arithmetic_matches_host_bit_for_bit():
     for name in ("fresnel", "point_light", "pow5", "atan2"):
         mm = re.search(r"^%s mismatches=(\d+) of (\d+)" % name, out.stdout, flags=re.M)
         assert mm and int(mm.group(1)) <= int(mm.group(2)) // 100000, out.stdout
+
+
+def test_short_forms_are_ieee_on_every_float():
+    """rcp3_rn, rcp_sqrt_rn and smith_term (srt_core.h) against the compiler's general IEEE sequences on the device, bit
+    for bit on all 2^32 inputs, and against the host's IEEE operations through a checksum over the same inputs."""
+    exe = os.path.join(helpers.ROOT, "tests", "gpu_probe", "exhaustive")
+    assert os.path.exists(exe), "build it with `make -C tests/gpu_probe` (done by __graft_entry__.build())"
+    out = subprocess.run([exe], capture_output=True, text=True, timeout=600)
+    print(out.stdout)
+    assert out.returncode == 0, out.stdout + out.stderr
+    assert re.search(r"^exhaustive_failures=0$", out.stdout, flags=re.M), out.stdout
+    for name in ("rcp3_rn", "rcp_sqrt_rn", "smith_term"):
+        m = re.search(r"^%s mismatches=(\d+) checksum_device=([0-9a-f]+) checksum_host=([0-9a-f]+)" % name, out.stdout, flags=re.M)
+        assert m and int(m.group(1)) == 0 and m.group(2) == m.group(3), out.stdout

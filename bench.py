@@ -64,8 +64,8 @@ CONFIGS = {
 # doubled, the correction for gfx950).  They are not re-measured by a normal run: a counter pass needs the profiler.
 # config -> (FETCH_SIZE KiB, WRITE_SIZE KiB, the profile the numbers come from)
 MEASURED_TRAFFIC_KIB = {
-    "c2": (3.869e5, 3.303e6, "profiles/r2b_c2_pmc_and_kernel_stats.txt"),   # trace_kernel<true,false,true>
-    "c3": (5.921e6, 7.030e6, "profiles/r2b_c3_pmc_and_kernel_stats.txt"),   # mesh_trace_kernel<false,false>
+    "c2": (3.909e5, 3.330e6, "profiles/r2c_c2_pmc_and_kernel_stats.txt"),   # trace_kernel<true,false,true>
+    "c3": (6.289e6, 7.314e6, "profiles/r2c_c3_pmc_and_kernel_stats.txt"),   # mesh_trace_kernel<false,false>
 }
 
 # Algorithmic work per event: bytes fetched / FP32 operations (add, sub, mul, div, sqrt, min, max, compare = 1 each)

@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define SRT_VERSION 201
+#define SRT_VERSION 300
 
 enum {
     SRT_OK = 0,
@@ -200,9 +200,16 @@ int  srt_set_rects(srt_ctx* ctx, const float* x1, const float* x2, const float* 
 int  srt_set_triangles(srt_ctx* ctx, const float* pos9, const float* nrm9, const uint32_t* material, const uint8_t* flags, uint32_t n);
 /* lights.lights (LightList of PointLight, RaytracingClasses.cs:195-203; Game1.cs:140-144). */
 int  srt_set_lights(srt_ctx* ctx, const srt_point_light* lights, uint32_t n);
+/* The order of world.surfaces (RaytracingClasses.cs:340), one ordered list across the three types: SurfaceList.hit scans
+ * it in that order and lets the later surface win an exact tie (:298-316), and the BVHNode constructor splits it by
+ * position (:387-425), so the order decides the shape of the reference tree.  Entry i names the i-th surface added to
+ * the world (world.surfaces.Add, Game1.cs:117-134; ModelLoader.cs:60): type[i] = 0 triangle, 1 sphere, 2 rect, and
+ * index[i] = its position in the array given to srt_set_triangles / srt_set_spheres / srt_set_rects.  Every surface of
+ * the world has to be named exactly once (srt_commit_scene checks it).  Optional: without it, or after a call with n = 0,
+ * the order is all triangles, then all spheres, then all rects -- the statement order of Game1.cs:112-134. */
+int  srt_set_surface_order(srt_ctx* ctx, const uint8_t* type, const uint32_t* index, uint32_t n);
 /* world.Init() + new BVHNode(world) (Game1.cs:136-137): flattens the scene, builds and linearises the BVH
- * (32-byte nodes) and uploads everything.  Insertion order of world.surfaces is taken to be
- * triangles, spheres, rects -- the statement order of Game1.cs:112-134. */
+ * (32-byte nodes) and uploads everything. */
 int  srt_commit_scene(srt_ctx* ctx, int world_kind);
 
 /* Replaces Parallel.For(0, N, startThread) + renderBlock + WritePixel (Game1.cs:165, 264-317;

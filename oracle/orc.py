@@ -77,6 +77,8 @@ def lib():
         L.orc_scene_create.restype = C.c_void_p
         L.orc_scene_create.argtypes = [C.POINTER(Material), C.c_int32, C.POINTER(Tri), C.c_int32, C.POINTER(Sphere), C.c_int32,
                                        C.POINTER(Rect), C.c_int32, C.POINTER(Light), C.c_int32]
+        L.orc_scene_create_ordered.restype = C.c_void_p
+        L.orc_scene_create_ordered.argtypes = L.orc_scene_create.argtypes + [C.POINTER(C.c_uint8), C.POINTER(C.c_uint32), C.c_int32]
         L.orc_scene_destroy.argtypes = [C.c_void_p]
         L.orc_scene_bvh_nodes.argtypes = [C.c_void_p]
         L.orc_scene_bvh_depth.argtypes = [C.c_void_p]
@@ -156,7 +158,9 @@ def tris_from_arrays(pos9, nrm9, material_index=0, flip=False, blend=True):
 class Scene:
     """world + lights as the reference's Game1.Initialize builds them (Game1.cs:96-144)."""
 
-    def __init__(self, materials, spheres=(), rects=(), tris=None, lights=()):
+    def __init__(self, materials, spheres=(), rects=(), tris=None, lights=(), order=None):
+        """order: (types, indices) -- world.surfaces entry by entry (type 0 triangle, 1 sphere, 2 rect; index into that
+        type's list); default: all triangles, then all spheres, then all rects."""
         L = lib()
         m, nm = _arr(Material, list(materials))
         s, ns = _arr(Sphere, list(spheres))
@@ -170,7 +174,13 @@ class Scene:
         else:
             t, nt = _arr(Tri, list(tris))
         self.n_prims = nt + ns + nr
-        self._h = L.orc_scene_create(m, nm, t, nt, s, ns, r, nr, li, nl)
+        if order is None:
+            self._h = L.orc_scene_create(m, nm, t, nt, s, ns, r, nr, li, nl)
+        else:
+            ot = np.ascontiguousarray(order[0], dtype=np.uint8)
+            oi = np.ascontiguousarray(order[1], dtype=np.uint32)
+            self._h = L.orc_scene_create_ordered(m, nm, t, nt, s, ns, r, nr, li, nl, ot.ctypes.data_as(C.POINTER(C.c_uint8)),
+                                                 oi.ctypes.data_as(C.POINTER(C.c_uint32)), len(ot))
         if not self._h:
             raise ValueError(L.orc_last_error().decode())
 

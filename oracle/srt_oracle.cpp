@@ -1048,6 +1048,14 @@ orc_scene* orc_scene_create(const orc_material* mats, int32_t n_mats, const orc_
                             const orc_sphere* spheres, int32_t n_spheres, const orc_rect* rects, int32_t n_rects,
                             const orc_light* lights, int32_t n_lights)
 {
+    return orc_scene_create_ordered(mats, n_mats, tris, n_tris, spheres, n_spheres, rects, n_rects, lights, n_lights, nullptr, nullptr, 0);
+}
+
+orc_scene* orc_scene_create_ordered(const orc_material* mats, int32_t n_mats, const orc_tri* tris, int32_t n_tris,
+                                    const orc_sphere* spheres, int32_t n_spheres, const orc_rect* rects, int32_t n_rects,
+                                    const orc_light* lights, int32_t n_lights,
+                                    const uint8_t* order_type, const uint32_t* order_index, int32_t n_order)
+{
     auto s = std::make_unique<orc_scene>();
     s->materials.resize(n_mats > 0 ? n_mats : 0);
     for (int i = 0; i < n_mats; i++) {
@@ -1088,6 +1096,22 @@ orc_scene* orc_scene_create(const orc_material* mats, int32_t n_mats, const orc_
     for (int i = 0; i < n_lights; i++)
         s->lights.lightArray.push_back(std::make_unique<PointLight>(A3(lights[i].position), lights[i].brightness, A3(lights[i].color)));
 
+    if (n_order > 0) {
+        // world.surfaces.Add in the caller's order (Game1.cs:117-134, ModelLoader.cs:60); primId stays the index by type
+        if ((size_t)n_order != s->prims.size()) { g_error = "the surface order does not name every surface once"; return nullptr; }
+        std::vector<Surface*> ordered;
+        std::vector<char> seen(s->prims.size(), 0);
+        for (int32_t r = 0; r < n_order; r++) {
+            const uint32_t t = order_type[r], i = order_index[r];
+            const int64_t count = t == 0 ? n_tris : (t == 1 ? n_spheres : (t == 2 ? n_rects : 0));
+            if ((int64_t)i >= count) { g_error = "the surface order names a surface that does not exist"; return nullptr; }
+            const size_t g = t == 0 ? i : (t == 1 ? (size_t)n_tris + i : (size_t)n_tris + (size_t)n_spheres + i);
+            if (seen[g]) { g_error = "the surface order names a surface twice"; return nullptr; }
+            seen[g] = 1;
+            ordered.push_back(s->prims[g].get());
+        }
+        s->world.surfaces.assign(ordered.begin(), ordered.end());
+    }
     s->empty = s->world.surfaces.empty();
     if (!s->empty) {
         // Game1.cs:136-137.  Init() snapshots the insertion order before the BVH builder's

@@ -74,6 +74,12 @@ orc_scene* orc_scene_create(const orc_material* mats, int32_t n_mats,
                             const orc_sphere* spheres, int32_t n_spheres,
                             const orc_rect* rects, int32_t n_rects,
                             const orc_light* lights, int32_t n_lights);
+/* The same with world.surfaces in the caller's order: entry r names the r-th surface added (type 0 triangle, 1 sphere,
+ * 2 rect; index into that type's array); every surface exactly once.  n_order = 0: the order above. */
+orc_scene* orc_scene_create_ordered(const orc_material* mats, int32_t n_mats, const orc_tri* tris, int32_t n_tris,
+                                    const orc_sphere* spheres, int32_t n_spheres, const orc_rect* rects, int32_t n_rects,
+                                    const orc_light* lights, int32_t n_lights,
+                                    const uint8_t* order_type, const uint32_t* order_index, int32_t n_order);
 void orc_scene_destroy(orc_scene*);
 /* number of BVHNode objects / max depth of the reference tree (0 if not built) */
 int32_t orc_scene_bvh_nodes(const orc_scene*);

@@ -77,6 +77,7 @@ SYMBOLS = [
     ("srt_set_rects", C.c_int, [_CTX, _FP, _FP, _FP, _FP, _FP, _UP, C.c_uint32]),
     ("srt_set_triangles", C.c_int, [_CTX, _FP, _FP, _UP, C.POINTER(C.c_uint8), C.c_uint32]),
     ("srt_set_lights", C.c_int, [_CTX, C.POINTER(PointLight), C.c_uint32]),
+    ("srt_set_surface_order", C.c_int, [_CTX, C.POINTER(C.c_uint8), C.POINTER(C.c_uint32), C.c_uint32]),
     ("srt_commit_scene", C.c_int, [_CTX, C.c_int]),
     ("srt_render", C.c_int, [_CTX, C.POINTER(RenderParams), C.c_void_p]),
     ("srt_render_device", C.c_int, [_CTX, C.POINTER(RenderParams), C.c_void_p, C.c_size_t, C.c_void_p]),

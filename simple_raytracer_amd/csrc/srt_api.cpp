@@ -690,6 +690,13 @@ int srt_set_lights(srt_ctx* c, const srt_point_light* l, uint32_t n)
     return host_set_lights(c->host, l, n, c->error);
 }
 
+int srt_set_surface_order(srt_ctx* c, const uint8_t* type, const uint32_t* index, uint32_t n)
+{
+    if (!c) return SRT_E_INVALID;
+    c->committed = false;
+    return host_set_surface_order(c->host, type, index, n, c->error);
+}
+
 int srt_commit_scene(srt_ctx* c, int world_kind)
 {
     if (!c) return SRT_E_INVALID;

@@ -178,11 +178,12 @@ struct ReferenceBuilder {
         nodes[slot].box = box;
         return box;
     }
-    void run()
+    // `insertion`: world.surfaces before the constructor runs (empty: surface i at position i)
+    void run(const std::vector<uint32_t>& insertion)
     {
         const uint32_t n = (uint32_t)pb.size();
         ids.resize(n);
-        for (uint32_t i = 0; i < n; i++) ids[i] = i;
+        for (uint32_t i = 0; i < n; i++) ids[i] = insertion.empty() ? i : insertion[i];
         nodes.assign(2, NodeRec());  // root + one unused slot so that sibling pairs start at even indices
         std::memset(nodes.data(), 0, sizeof(NodeRec) * 2);
         leaf_order.reserve(n);
@@ -652,6 +653,15 @@ int host_set_triangles(HostScene& s, const float* pos9, const float* nrm9, const
     return SRT_OK;
 }
 
+int host_set_surface_order(HostScene& s, const uint8_t* type, const uint32_t* index, uint32_t n, std::string& err)
+{
+    if (n && (!type || !index)) { err = "surface order array is NULL"; return SRT_E_INVALID; }
+    // kept as (type, index) pairs until the commit: the surface arrays may still change
+    s.order_type.assign(type, type + n);
+    s.order_index.assign(index, index + n);
+    return SRT_OK;
+}
+
 int host_set_lights(HostScene& s, const srt_point_light* l, uint32_t n, std::string& err)
 {
     if (n && !l) { err = "lights is NULL"; return SRT_E_INVALID; }
@@ -735,6 +745,24 @@ int flatten_scene(const HostScene& in, int world_kind, FlatScene& out, std::stri
         err = "RectAxis has no boundingBox(): new BVHNode(world) throws NullReferenceException in the reference; use SRT_WORLD_SURFACELIST";
         return SRT_E_REFERENCE;
     }
+    // world.surfaces: `insertion[r]` = global index of the r-th surface added, `rank[g]` = position of surface g
+    // (both empty for the default order, in which they are the identity)
+    std::vector<uint32_t> insertion, rank;
+    if (!in.order_type.empty()) {
+        if (in.order_type.size() != total) { err = "the surface order names " + std::to_string(in.order_type.size()) + " surfaces, the world has " + std::to_string(total); return SRT_E_INVALID; }
+        insertion.resize((size_t)total);
+        rank.assign((size_t)total, 0xFFFFFFFFu);
+        for (uint32_t r = 0; r < (uint32_t)total; r++) {
+            const uint32_t t = in.order_type[r], i = in.order_index[r];
+            const uint32_t count = t == PRIM_TRI ? nt : (t == PRIM_SPHERE ? ns : (t == PRIM_RECT ? nr : 0u));
+            if (i >= count) { err = "surface order entry " + std::to_string(r) + " names a surface that does not exist"; return SRT_E_INVALID; }
+            const uint32_t g = t == PRIM_TRI ? i : (t == PRIM_SPHERE ? nt + i : nt + ns + i);
+            if (rank[g] != 0xFFFFFFFFu) { err = "surface order entry " + std::to_string(r) + " names a surface for the second time"; return SRT_E_INVALID; }
+            rank[g] = r;
+            insertion[r] = g;
+        }
+    }
+    auto rank_of = [&](uint32_t g) { return rank.empty() ? g : rank[g]; };
 
     for (const srt_material& m : in.materials) {
         out.materials.push_back(mkq(m.albedo[0], m.albedo[1], m.albedo[2], m.metalness));
@@ -814,7 +842,7 @@ int flatten_scene(const HostScene& in, int world_kind, FlatScene& out, std::stri
     if (n_boxed > 0 && !tiny && (world_kind == SRT_WORLD_BVHNODE || !members.empty())) {
         if (world_kind == SRT_WORLD_BVHNODE) {
             ReferenceBuilder b(pb);
-            b.run();
+            b.run(insertion);
             for (uint32_t i = 0; i < b.leaf_order.size(); i++) emit_prim(in, b.leaf_order[i], i, prims + (size_t)i * 3);
             emit_nodes(b.nodes, out.nodes);
             out.leaf_order = b.leaf_order;
@@ -831,7 +859,7 @@ int flatten_scene(const HostScene& in, int world_kind, FlatScene& out, std::stri
             SahBuilder b(pb);
             b.run(std::move(members));
             parallel_slices((uint32_t)b.leaf_order.size(), [&](uint32_t first, uint32_t last) {
-                for (uint32_t i = first; i < last; i++) emit_prim(in, b.leaf_order[i], b.leaf_order[i], prims + (size_t)i * 3);
+                for (uint32_t i = first; i < last; i++) emit_prim(in, b.leaf_order[i], rank_of(b.leaf_order[i]), prims + (size_t)i * 3);
             });
             n_tree = (uint32_t)b.leaf_order.size();
             WideBuilder w(b.nodes);
@@ -846,11 +874,13 @@ int flatten_scene(const HostScene& in, int world_kind, FlatScene& out, std::stri
         out.has_bvh = 1;
         // scanned linearly after the tree: the surfaces kept out of it, then the rects
         out.list_first = n_tree;
-        for (uint32_t i = 0; i < (uint32_t)strays.size(); i++) emit_prim(in, strays[i], strays[i], prims + (size_t)(n_tree + i) * 3);
-        for (uint32_t i = 0; i < nr; i++) emit_prim(in, n_boxed + i, n_boxed + i, prims + (size_t)(n_boxed + i) * 3);
+        for (uint32_t i = 0; i < (uint32_t)strays.size(); i++) emit_prim(in, strays[i], rank_of(strays[i]), prims + (size_t)(n_tree + i) * 3);
+        for (uint32_t i = 0; i < nr; i++) emit_prim(in, n_boxed + i, rank_of(n_boxed + i), prims + (size_t)(n_boxed + i) * 3);
         out.list_count = (uint32_t)strays.size() + nr;
     } else {
-        for (uint32_t g = 0; g < (uint32_t)total; g++) emit_prim(in, g, g, prims + (size_t)g * 3);
+        // a world that is scanned as a list is laid out in the order of the list: the scan then meets the surfaces as
+        // SurfaceList.hit does, NaN distances included
+        for (uint32_t r = 0; r < (uint32_t)total; r++) emit_prim(in, insertion.empty() ? r : insertion[r], r, prims + (size_t)r * 3);
         out.list_first = 0;
         out.list_count = (uint32_t)total;
         out.has_bvh = 0;

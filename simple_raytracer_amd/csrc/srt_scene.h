@@ -12,9 +12,10 @@
 namespace srt {
 
 // What the srt_set_* calls copied from the caller: the reference's world.surfaces /
-// lights.lights / materials, by type.  Global surface index ("insertion order"):
-// triangles first, then spheres, then rects.
+// lights.lights / materials, by type.  Global surface index: triangles first, then spheres, then rects.
 struct HostScene {
+    std::vector<uint8_t> order_type;      // srt_set_surface_order: world.surfaces entry by entry (empty: triangles, spheres, rects)
+    std::vector<uint32_t> order_index;
     std::vector<srt_material> materials;
     std::vector<float> tri_pos, tri_nrm;  // 9 floats per triangle
     std::vector<uint32_t> tri_mat;
@@ -35,7 +36,7 @@ struct FlatScene {
     uint32_t n_lights = 0, list_first = 0, list_count = 0, has_bvh = 0, n_tiny = 0, n_wide = 0;
     uint32_t n_nodes = 0, bvh_depth = 0, n_prims = 0, n_materials = 0;
     uint32_t n_tree_nodes = 0;   // nodes of the tree itself: BVHNode objects of the reference tree (its array has one unused slot), or wide nodes
-    // SRT_WORLD_BVHNODE: the surfaces (global index: triangles, spheres, rects) in the order the reference tree's leaves
+    // SRT_WORLD_BVHNODE: the surfaces (global index: all triangles, then all spheres, then all rects) in the order the reference tree's leaves
     // hold them, left to right -- the order BVHNode.hit visits them in.  Host-side only (tests compare it).
     std::vector<uint32_t> leaf_order;
     // far-origin guard of the library's own tree (SceneView::far_*); far_L0 = infinity when there is no such tree
@@ -68,6 +69,7 @@ int host_set_spheres(HostScene& s, const float* cx, const float* cy, const float
 int host_set_rects(HostScene& s, const float* x1, const float* x2, const float* y1, const float* y2, const float* k, const uint32_t* mat, uint32_t n, std::string& err);
 int host_set_triangles(HostScene& s, const float* pos9, const float* nrm9, const uint32_t* mat, const uint8_t* flags, uint32_t n, std::string& err);
 int host_set_lights(HostScene& s, const srt_point_light* l, uint32_t n, std::string& err);
+int host_set_surface_order(HostScene& s, const uint8_t* type, const uint32_t* index, uint32_t n, std::string& err);
 
 // Validates render parameters and derives the kernel arguments (tile grid, work item count).
 int make_render_args(const srt_render_params* p, const Camera& cam, RenderArgs& ra, std::string& err);

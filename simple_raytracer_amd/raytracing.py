@@ -170,8 +170,9 @@ class SurfaceList(Surface):
         self.surfaceArray = list(self.surfaces)
 
     def flatten(self):
-        """-> dict of the arrays the C ABI takes.  Surfaces are bucketed by type; inside a type the insertion
-        order is kept; across types the order is triangles, spheres, rects (Game1.cs:112-134)."""
+        """-> dict of the arrays the C ABI takes.  Surfaces are bucketed by type, and inside a type the insertion order
+        is kept; "order_type" / "order_index" name the surfaces in the order of world.surfaces itself (type 0 triangle,
+        1 sphere, 2 rect; index into that type's array), which is what srt_set_surface_order takes."""
         mats, mat_index = [], {}
 
         def mid(m):
@@ -182,20 +183,27 @@ class SurfaceList(Surface):
 
         sph, sph_m, rect, rect_m = [], [], [], []
         tp, tn, tm, tf = [], [], [], []
+        ot, oi, n_tri = [], [], 0     # world.surfaces entry by entry: type (0 triangle, 1 sphere, 2 rect), index inside the type
         for s in self.surfaces:
             if isinstance(s, Sphere):
+                ot.append(np.array([1], dtype=np.uint8)); oi.append(np.array([len(sph)], dtype=np.uint32))
                 sph.append([s.origin[0], s.origin[1], s.origin[2], s.radius])
                 sph_m.append(mid(s.material))
             elif isinstance(s, RectAxis):
+                ot.append(np.array([2], dtype=np.uint8)); oi.append(np.array([len(rect)], dtype=np.uint32))
                 rect.append([s.x1, s.x2, s.y1, s.y2, s.k])
                 rect_m.append(mid(s.material))
             elif isinstance(s, Tri):
+                ot.append(np.zeros(1, dtype=np.uint8)); oi.append(np.array([n_tri], dtype=np.uint32))
+                n_tri += 1
                 tp.append(np.concatenate([v.position for v in s.verts])[None, :])
                 tn.append(np.concatenate([v.normal for v in s.verts])[None, :])
                 tm.append(np.array([mid(s.material)], dtype=np.uint32))
                 tf.append(np.array([(1 if s.flipNormal else 0) | (2 if s.blend else 0)], dtype=np.uint8))
             elif isinstance(s, TriMesh):
                 n = s.pos9.shape[0]
+                ot.append(np.zeros(n, dtype=np.uint8)); oi.append(np.arange(n_tri, n_tri + n, dtype=np.uint32))
+                n_tri += n
                 tp.append(s.pos9)
                 tn.append(s.nrm9)
                 tm.append(np.full(n, mid(s.material), dtype=np.uint32))
@@ -210,4 +218,5 @@ class SurfaceList(Surface):
             "rects": np.array(rect, dtype=np.float32).reshape(-1, 5), "rect_mat": np.array(rect_m, dtype=np.uint32),
             "tri_pos": cat(tp, 9, np.float32), "tri_nrm": cat(tn, 9, np.float32),
             "tri_mat": cat(tm, 0, np.uint32), "tri_flags": cat(tf, 0, np.uint8),
+            "order_type": cat(ot, 0, np.uint8), "order_index": cat(oi, 0, np.uint32),
         }

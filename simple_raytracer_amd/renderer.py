@@ -85,6 +85,13 @@ class Renderer:
         tp, tn = flat["tri_pos"], flat["tri_nrm"]
         self._check(L.srt_set_triangles(self._ctx, _fp(tp), _fp(tn), _up(flat["tri_mat"]),
                                         flat["tri_flags"].ctypes.data_as(C.POINTER(C.c_uint8)), len(tp)))
+        # world.surfaces as one ordered list; triangles, spheres, rects is the library's default and needs no call
+        ot, oi = flat["order_type"], flat["order_index"]
+        first = np.array([0, len(tp), len(tp) + len(s)], dtype=np.int64)    # global index: all triangles, then all spheres, then all rects
+        if not np.array_equal(first[ot] + oi, np.arange(len(ot), dtype=np.int64)):
+            self._check(L.srt_set_surface_order(self._ctx, ot.ctypes.data_as(C.POINTER(C.c_uint8)), _up(oi), len(ot)))
+        else:
+            self._check(L.srt_set_surface_order(self._ctx, None, None, 0))
         ll = lights.lights
         larr = (N.PointLight * max(len(ll), 1))()
         for i, l in enumerate(ll):

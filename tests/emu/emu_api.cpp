@@ -173,6 +173,7 @@ int srt_set_triangles(srt_ctx* c, const float* pos9, const float* nrm9, const ui
     return host_set_triangles(c->host, pos9, nrm9, mat, flags, n, c->error);
 }
 int srt_set_lights(srt_ctx* c, const srt_point_light* l, uint32_t n) { c->committed = false; return host_set_lights(c->host, l, n, c->error); }
+int srt_set_surface_order(srt_ctx* c, const uint8_t* type, const uint32_t* index, uint32_t n) { c->committed = false; return host_set_surface_order(c->host, type, index, n, c->error); }
 
 int srt_commit_scene(srt_ctx* c, int world_kind)
 {

@@ -34,6 +34,8 @@ class SceneSpec:
         self.meshes = []      # (pos9 (n,9), nrm9 (n,9), material, flip, blend)
         self.lights = []      # (position3, brightness, color3 or None)
         self.camera = ((0, 0, 0), (0, 0, -1), 60.0)
+        # world.surfaces entry by entry: ("mesh", i) / ("sphere", j) / ("rect", k); None = meshes, spheres, rects
+        self.order = None
 
     # -- oracle side ---------------------------------------------------------------------------
     def oracle_scene(self):
@@ -44,7 +46,19 @@ class SceneSpec:
         if self.meshes:
             tris = np.concatenate([orc.tris_from_arrays(p, n, mi, fl, bl) for p, n, mi, fl, bl in self.meshes])
         lights = [orc.point_light(p, b, c) for p, b, c in self.lights]
-        return orc.Scene(mats, spheres=spheres, rects=rects, tris=tris, lights=lights)
+        order = None
+        if self.order is not None:
+            first = np.concatenate([[0], np.cumsum([len(m[0]) for m in self.meshes])]).astype(np.int64)
+            types, indices = [], []
+            for kind, i in self.order:
+                if kind == "mesh":
+                    types.append(np.zeros(first[i + 1] - first[i], dtype=np.uint8))
+                    indices.append(np.arange(first[i], first[i + 1], dtype=np.uint32))
+                else:
+                    types.append(np.array([1 if kind == "sphere" else 2], dtype=np.uint8))
+                    indices.append(np.array([i], dtype=np.uint32))
+            order = (np.concatenate(types), np.concatenate(indices))
+        return orc.Scene(mats, spheres=spheres, rects=rects, tris=tris, lights=lights, order=order)
 
     def oracle_camera(self, width, height):
         o, l, fov = self.camera
@@ -54,12 +68,20 @@ class SceneSpec:
     def host(self, width, height):
         mats = [srt.Material(a, m, s, e) for a, m, s, e in self.materials]
         world = srt.SurfaceList()
-        for p, n, mi, fl, bl in self.meshes:
-            world.surfaces.append(srt.TriMesh(p, n, mats[mi], fl, bl))
-        for c, r, mi in self.spheres:
-            world.surfaces.append(srt.Sphere(c, r, mats[mi]))
-        for r in self.rects:
-            world.surfaces.append(srt.RectAxis(r[0], r[1], r[2], r[3], r[4], mats[r[5]]))
+        order = self.order
+        if order is None:
+            order = [("mesh", i) for i in range(len(self.meshes))] + [("sphere", i) for i in range(len(self.spheres))] + \
+                    [("rect", i) for i in range(len(self.rects))]
+        for kind, i in order:
+            if kind == "mesh":
+                p, n, mi, fl, bl = self.meshes[i]
+                world.surfaces.append(srt.TriMesh(p, n, mats[mi], fl, bl))
+            elif kind == "sphere":
+                c, r, mi = self.spheres[i]
+                world.surfaces.append(srt.Sphere(c, r, mats[mi]))
+            else:
+                r = self.rects[i]
+                world.surfaces.append(srt.RectAxis(r[0], r[1], r[2], r[3], r[4], mats[r[5]]))
         world.Init()
         lights = srt.LightList()
         for p, b, c in self.lights:
@@ -183,6 +205,29 @@ def mesh_spec(kind="sphere", n=16, with_spheres=True, with_rect=False):
         s.rects = [(-3, 3, -3, 1, 9.0, 1)]  # RectAxis evaluates t = -k - o.z/d.z: with o.z = 0 the plane sits at z = -9 for d.z = -1 rays
     s.lights = [((4.0, -3.0, 1.0), 5.0, None), ((-3.0, -2.0, -2.0), 2.0, (1.2, 0.4, 0.4))]
     s.camera = ((0, 0, 0), (0.0, 0.2, -6.0), 55)
+    return s
+
+
+def reordered_spec(kind):
+    """Worlds whose surfaces were not added type by type: world.surfaces is one ordered list (RaytracingClasses.cs:340), the
+    BVHNode constructor splits it by position (:387-425) and SurfaceList.hit lets the later surface win a tie (:298-316).
+    "spheres-first": mesh_spec() with its spheres added before the meshes, as Game1.cs:117-122 followed by
+    ModelLoader.CreateScene would; "interleaved": a sphere, the ground grid, a sphere, the mesh, a sphere;
+    "game1-reversed": the Game1 spheres in reverse order; "rect-between": the Game1 scene with its rect added second."""
+    if kind == "game1-reversed":
+        s = default_spec()
+        s.order = [("sphere", i) for i in reversed(range(len(s.spheres)))]
+    elif kind == "rect-between":
+        s = default_spec(with_rect=True)
+        s.order = [("sphere", 0), ("rect", 0)] + [("sphere", i) for i in range(1, len(s.spheres))]
+    else:
+        s = mesh_spec(n=8)
+        if kind == "spheres-first":
+            s.order = [("sphere", 0), ("sphere", 1), ("sphere", 2), ("mesh", 0), ("mesh", 1)]
+        elif kind == "interleaved":
+            s.order = [("sphere", 2), ("mesh", 1), ("sphere", 0), ("mesh", 0), ("sphere", 1)]
+        else:
+            raise ValueError(kind)
     return s
 
 

@@ -59,6 +59,11 @@ CASES = [
     ("stray-1e20-bvhnode", lambda: helpers.stray_spec("1e20"), 48, 27, 1, 3, COLOR, BVH, 2),
     ("stray-nan-bvhnode", lambda: helpers.stray_spec("nan"), 48, 27, 1, 3, COLOR, BVH, 2),
 ]
+# world.surfaces in an order of the caller's instead of triangles, spheres, rects (srt_set_surface_order)
+for _k in ("spheres-first", "interleaved", "game1-reversed"):
+    CASES.append(("order-%s-bvhnode" % _k, (lambda k=_k: helpers.reordered_spec(k)), 96, 54, 2, 5, COLOR, BVH, 8))
+    CASES.append(("order-%s-list" % _k, (lambda k=_k: helpers.reordered_spec(k)), 96, 54, 2, 5, COLOR, LIST, 8))
+CASES.append(("order-rect-between-list", lambda: helpers.reordered_spec("rect-between"), 96, 54, 2, 4, COLOR, LIST, 8))
 # cameras far from the scene: the float surface tests accept rays that miss their surface by a wide margin there
 # (helpers.far_camera_spec); the library's tree has to return those hits like the list scan does
 for _d in (1e3, 1e4, 1e6):

@@ -22,9 +22,13 @@ SCENES = {
     "mesh+spheres": (lambda: helpers.mesh_spec(), 64, 36, 1, 4),
     "mesh-only": (lambda: helpers.mesh_spec(with_spheres=False), 48, 27, 1, 3),
     "teapot.dae": (lambda: helpers.teapot_spec(), 48, 27, 1, 2),
+    # world.surfaces in an order of the caller's (srt_set_surface_order): another list, another tree
+    "spheres-first": (lambda: helpers.reordered_spec("spheres-first"), 48, 27, 1, 3),
+    "interleaved": (lambda: helpers.reordered_spec("interleaved"), 48, 27, 1, 3),
+    "game1-reversed": (lambda: helpers.reordered_spec("game1-reversed"), 64, 36, 2, 6),
 }
 
-STACK_WALKED = ("mesh+spheres", "mesh-only", "teapot.dae")   # trees too large for the stackless walk
+STACK_WALKED = ("mesh+spheres", "mesh-only", "teapot.dae", "spheres-first", "interleaved")   # trees too large for the stackless walk
 
 
 def run(renderer, orc, name):
@@ -53,3 +57,26 @@ def check_counts(st, ost):
         assert st[kind + "_tests"] == expect, (kind, st[kind + "_tests"], ost[kind + "_tests"], ost[kind + "_repeats"], ost[kind + "_inert"], unasked)
     assert st["box_tests"] > 0
     return unasked
+
+
+def insertion_ranks(name, leaf_order, oracle_side=False):
+    """Leaf order as positions in world.surfaces.  The two sides number the surfaces by type (all triangles, then all spheres,
+    then all rects), but the host mirror fills its per-type arrays in the order of world.surfaces while the oracle is handed
+    the scene description's own arrays, so the same surface can carry different numbers on the two sides; its position in
+    world.surfaces is the same."""
+    spec = SCENES[name][0]()
+    if oracle_side:
+        if spec.order is None:
+            return np.asarray(leaf_order)
+        first = np.concatenate([[0], np.cumsum([len(m[0]) for m in spec.meshes])]).astype(np.int64)
+        n_tri = int(first[-1])
+        surfaces = []
+        for kind, i in spec.order:
+            surfaces.extend(range(first[i], first[i + 1]) if kind == "mesh" else [n_tri + i if kind == "sphere" else n_tri + len(spec.spheres) + i])
+    else:
+        flat = spec.host(8, 8)[0].flatten()
+        first = np.array([0, len(flat["tri_pos"]), len(flat["tri_pos"]) + len(flat["spheres"])], dtype=np.int64)
+        surfaces = first[flat["order_type"]] + flat["order_index"]
+    rank = np.empty(len(surfaces), dtype=np.int64)
+    rank[np.asarray(surfaces, dtype=np.int64)] = np.arange(len(surfaces))
+    return rank[np.asarray(leaf_order, dtype=np.int64)]

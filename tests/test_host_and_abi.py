@@ -71,7 +71,7 @@ def test_library_loads_and_exports_every_declared_symbol():
     lib = _native.load()
     for name in _declared_symbols():
         assert hasattr(lib, name), name
-    assert lib.srt_version() == 201
+    assert lib.srt_version() == 300
     # struct sizes the header promises
     assert C.sizeof(_native.Material) == 32 and C.sizeof(_native.PointLight) == 28
 

@@ -32,6 +32,50 @@ def test_rects_are_rejected_for_bvhnode_worlds(emu):
     assert e.value.code == srt._native.E_REFERENCE
 
 
+def test_surface_order_must_name_every_surface_once(emu):
+    """srt_set_surface_order (world.surfaces as one ordered list, RaytracingClasses.cs:340): the commit refuses an order that
+    leaves a surface out, names one twice or names one that does not exist; n = 0 goes back to triangles, spheres, rects."""
+    import ctypes as C
+    import numpy as np
+    import helpers
+    world, lights, cam = helpers.default_spec().host(32, 18)     # five spheres
+    emu.set_scene(world, lights, cam, world_kind=srt.WORLD_BVHNODE)
+    lib, ctx = emu._lib, emu._ctx
+
+    def commit_with(types, indices):
+        t, i = np.array(types, dtype=np.uint8), np.array(indices, dtype=np.uint32)
+        assert lib.srt_set_surface_order(ctx, t.ctypes.data_as(C.POINTER(C.c_uint8)), i.ctypes.data_as(C.POINTER(C.c_uint32)), len(t)) == 0
+        return lib.srt_commit_scene(ctx, srt.WORLD_BVHNODE)
+
+    assert commit_with([1] * 5, [4, 3, 2, 1, 0]) == 0
+    assert commit_with([1] * 4, [0, 1, 2, 3]) == srt._native.E_INVALID          # one surface left out
+    assert commit_with([1] * 5, [0, 1, 2, 3, 3]) == srt._native.E_INVALID       # one named twice
+    assert commit_with([1] * 5, [0, 1, 2, 3, 5]) == srt._native.E_INVALID       # no such sphere
+    assert commit_with([1, 1, 1, 1, 0], [0, 1, 2, 3, 0]) == srt._native.E_INVALID   # no such triangle
+    assert commit_with([1, 1, 1, 1, 3], [0, 1, 2, 3, 4]) == srt._native.E_INVALID   # no such type
+    assert lib.srt_set_surface_order(ctx, None, None, 0) == 0
+    assert lib.srt_commit_scene(ctx, srt.WORLD_BVHNODE) == 0
+
+
+def test_surface_order_changes_the_reference_tree(emu, oracle):
+    """The same surfaces added in another order give another BVHNode tree (the constructor splits world.surfaces by
+    position, RaytracingClasses.cs:387-425): the order handed over through srt_set_surface_order must reach the builder."""
+    import ctypes as C
+    import numpy as np
+    import helpers
+    orders = {}
+    for kind in (None, "spheres-first", "interleaved"):
+        spec = helpers.mesh_spec(n=8) if kind is None else helpers.reordered_spec(kind)
+        world, lights, cam = spec.host(32, 18)
+        emu.set_scene(world, lights, cam, world_kind=srt.WORLD_BVHNODE)
+        emu.render(32, 18, samples=1, max_depth=1, counted=True)
+        st = emu.stats()
+        osc = spec.oracle_scene()
+        assert (st["bvh_nodes"], st["bvh_depth"]) == (osc.bvh_nodes(), osc.bvh_depth())
+        orders[kind] = (st["bvh_nodes"], st["bvh_depth"], st["box_tests"])
+    assert len(set(orders.values())) == 3, orders     # three orders, three different trees
+
+
 def test_empty_world_renders_sky(emu, oracle):
     import helpers
     spec = helpers.SceneSpec()
@@ -191,7 +235,7 @@ def test_reference_tree_is_the_oracles_tree(emu, oracle, name):
     order = np.empty(st["n_prims"], np.uint32)
     n = fn(emu._ctx, order.ctypes.data_as(C.c_void_p), C.c_uint64(len(order)))
     assert n == st["n_prims"]
-    assert list(order) == list(osc.bvh_leaf_order())
+    assert list(reference_tree.insertion_ranks(name, order)) == list(reference_tree.insertion_ranks(name, osc.bvh_leaf_order(), oracle_side=True))
 
 
 INERT_KINDS = ("plain", "mirror", "rough", "huge-brightness", "huge-light", "nan-metal")

@@ -60,6 +60,12 @@ struct RcclApi {
         Send = reinterpret_cast<decltype(Send)>(sym("ncclSend"));
         Recv = reinterpret_cast<decltype(Recv)>(sym("ncclRecv"));
         GetErrorString = reinterpret_cast<decltype(GetErrorString)>(sym("ncclGetErrorString"));
+        if (!ok) {
+            // a library without the whole interface is no library: the next context that asks gets the same answer
+            // instead of a call through a null pointer
+            dlclose(handle);
+            handle = nullptr;
+        }
         return ok;
     }
 };
@@ -78,6 +84,7 @@ struct DeviceState {
     uint32_t* d_counter = nullptr;        // work counter of the persistent trace kernel
     float* d_timeline = nullptr;          // scratch of -DSRT_TIMELINE builds (per-wavefront clock records)
     void* d_frame_slab = nullptr;         // frames of pending ray-tree nodes, one part per wavefront of the grid
+    size_t slab_bytes = 0;                // its size: trace_frame_slab_bytes(), or less when SRT_FRAME_SLAB_MB bounds it
     float* d_samples = nullptr;           // per-(sample, pixel) colours of one pass, 12 bytes each
     size_t samples_capacity = 0;          // bytes
     float* d_running = nullptr;           // per-pixel running sums, only for renders that need several passes
@@ -338,11 +345,21 @@ int launch(srt_ctx* c, DeviceState& d, const srt_render_params* p, uint32_t* d_o
         ws.running = d.d_running; ws.running_bytes = d.running_capacity;
         ws.counter = d.d_counter;
     }
+    // A launch that is being recorded into a HIP graph (stream capture) runs later, perhaps many times: it is neither
+    // timed nor ordered against this device's earlier launches (the caller orders a graph against other work), and it
+    // leaves the context's events alone -- an event recorded under capture can never be waited for or read, which would
+    // fail every later collection.  The counters of its replays are added to the next collection's.
+    hipStreamCaptureStatus capture = hipStreamCaptureStatusNone;
+    const bool recorded = hipStreamIsCapturing(stream, &capture) == hipSuccess && capture == hipStreamCaptureStatusActive;
+    (void)hipGetLastError();
+    if (recorded && (progressive || mix_buffers > 0)) return fail(c, SRT_E_STATE, "this render cannot be recorded into a graph");
     // launches of one device share its workspace, counters and events: one on another stream waits for the last one
-    if (d.launched && d.last_stream != stream) SRT_HIP(c, hipStreamWaitEvent(stream, d.ev_end, 0));
-    d.last_stream = stream;
-    d.launched = true;
-    SRT_HIP(c, hipEventRecord(d.ev_begin, stream));
+    if (!recorded) {
+        if (d.launched && d.last_stream != stream) SRT_HIP(c, hipStreamWaitEvent(stream, d.ev_end, 0));
+        d.last_stream = stream;
+        d.launched = true;
+        SRT_HIP(c, hipEventRecord(d.ev_begin, stream));
+    }
     const SceneView view = scene_view(c, d);
     const bool exact = c->world_kind == SRT_WORLD_BVHNODE;
     if (mix_buffers > 0) {
@@ -352,7 +369,7 @@ int launch(srt_ctx* c, DeviceState& d, const srt_render_params* p, uint32_t* d_o
             ra.sample_first = (uint32_t)b;
             ra.sample_count = 1u;
             ra.n_items = ra.n_work;
-            hipError_t e = launch_trace(view, ra, exact, counted, ws.samples, d.d_stats, ws.counter, d.d_timeline, d.d_frame_slab, stream, d.walk_tune);
+            hipError_t e = launch_trace(view, ra, exact, counted, ws.samples, d.d_stats, ws.counter, d.d_timeline, d.d_frame_slab, d.slab_bytes, stream, d.walk_tune);
             if (e != hipSuccess) return hip_fail(c, e, "trace kernel launch");
             e = launch_resolve(ra, ws.samples, ws.running, c->d_mix, true, true, 0.0f, stream);
             if (e != hipSuccess) return hip_fail(c, e, "resolve kernel launch");
@@ -368,7 +385,7 @@ int launch(srt_ctx* c, DeviceState& d, const srt_render_params* p, uint32_t* d_o
         ra.sample_first = s0;
         ra.sample_count = (uint32_t)ra.samples - s0 < (uint32_t)per_pass ? (uint32_t)ra.samples - s0 : (uint32_t)per_pass;
         ra.n_items = ra.n_work * ra.sample_count;
-        hipError_t e = launch_trace(view, ra, exact, counted, ws.samples, d.d_stats, ws.counter, d.d_timeline, d.d_frame_slab, stream, d.walk_tune);
+        hipError_t e = launch_trace(view, ra, exact, counted, ws.samples, d.d_stats, ws.counter, d.d_timeline, d.d_frame_slab, d.slab_bytes, stream, d.walk_tune);
         if (e != hipSuccess) return hip_fail(c, e, "trace kernel launch");
         const uint32_t done = s0 + ra.sample_count;
         const float preview = progressive ? (float)ra.samples / (float)done : 0.0f;
@@ -381,8 +398,10 @@ int launch(srt_ctx* c, DeviceState& d, const srt_render_params* p, uint32_t* d_o
         }
     }
     if (&d == &c->dev[0]) c->passes_total = progressive ? pass : 0;
-    SRT_HIP(c, hipEventRecord(d.ev_end, stream));
-    d.stats_pending = true;
+    if (!recorded) {
+        SRT_HIP(c, hipEventRecord(d.ev_end, stream));
+        d.stats_pending = true;
+    }
     return SRT_OK;
 }
 
@@ -412,20 +431,31 @@ struct HipDevices {
         uint32_t* out = k == 0 ? c->d_gathered : d.d_out;
         return launch(c, d, &plan.part[k], out, (size_t)plan.pixels[k], d.stream, counted);
     }
+    // one receive on the first device, one send on device k (inside the caller's group)
+    int gather_pair(const MultiPlan& plan, int k)
+    {
+        DeviceState& root = c->dev[0];
+        SRT_HIP(c, hipSetDevice(root.device));
+        SRT_NCCL(c, g_rccl.Recv(c->d_gathered + (size_t)k * (size_t)plan.stride, (size_t)plan.pixels[k], ncclUint32, k, c->comms[0], root.stream));
+        SRT_HIP(c, hipSetDevice(c->dev[k].device));
+        SRT_NCCL(c, g_rccl.Send(c->dev[k].d_out, (size_t)plan.pixels[k], ncclUint32, 0, c->comms[k], c->dev[k].stream));
+        return SRT_OK;
+    }
     int gather(const MultiPlan& plan)
     {
         DeviceState& root = c->dev[0];
         if (c->gather == SRT_GATHER_RCCL) {
             // every peer has its own xGMI link to the first device: (n - 1) receives there, one send on each peer
             SRT_NCCL(c, g_rccl.GroupStart());
-            for (int k = 1; k < plan.n; k++) {
+            int rc = SRT_OK;
+            for (int k = 1; k < plan.n && rc == SRT_OK; k++) {
                 if (plan.pixels[k] == 0) continue;
-                SRT_HIP(c, hipSetDevice(root.device));
-                SRT_NCCL(c, g_rccl.Recv(c->d_gathered + (size_t)k * (size_t)plan.stride, (size_t)plan.pixels[k], ncclUint32, k, c->comms[0], root.stream));
-                SRT_HIP(c, hipSetDevice(c->dev[k].device));
-                SRT_NCCL(c, g_rccl.Send(c->dev[k].d_out, (size_t)plan.pixels[k], ncclUint32, 0, c->comms[k], c->dev[k].stream));
+                rc = gather_pair(plan, k);
             }
-            SRT_NCCL(c, g_rccl.GroupEnd());
+            // the group is closed whatever happened inside it: an open group would swallow the thread's later RCCL calls
+            const ncclResult_t end = g_rccl.GroupEnd();
+            if (rc != SRT_OK) return rc;
+            SRT_NCCL(c, end);
             return SRT_OK;
         }
         for (int k = 1; k < plan.n; k++) {
@@ -491,6 +521,14 @@ int render_blocking(srt_ctx* c, const srt_render_params* p, uint32_t* rgba_out, 
 int create_device(DeviceState& d, int ordinal)
 {
     d.device = ordinal;
+    // The frame slab is the one large standing allocation of a device (320 MiB for the largest grid).  SRT_FRAME_SLAB_MB
+    // bounds it, for hosts that share the GPU with a display: the persistent grid then has fewer blocks (256 KiB each).
+    d.slab_bytes = trace_frame_slab_bytes();
+    if (const char* mb = std::getenv("SRT_FRAME_SLAB_MB")) {
+        const long v = std::atol(mb);
+        if (v > 0 && ((size_t)v << 20) < d.slab_bytes) d.slab_bytes = (size_t)v << 20;
+        if (d.slab_bytes < 16 * trace_frame_slab_block_bytes()) d.slab_bytes = 16 * trace_frame_slab_block_bytes();
+    }
     bool ok = hipSetDevice(ordinal) == hipSuccess && hipStreamCreateWithFlags(&d.stream, hipStreamNonBlocking) == hipSuccess &&
               hipEventCreate(&d.ev_begin) == hipSuccess && hipEventCreate(&d.ev_end) == hipSuccess &&
               hipEventCreateWithFlags(&d.ev_tiles, hipEventDisableTiming) == hipSuccess &&
@@ -499,7 +537,7 @@ int create_device(DeviceState& d, int ordinal)
 #ifdef SRT_TIMELINE
               hipMalloc((void**)&d.d_timeline, trace_timeline_bytes()) == hipSuccess &&
 #endif
-              hipMalloc(&d.d_frame_slab, trace_frame_slab_bytes()) == hipSuccess &&
+              hipMalloc(&d.d_frame_slab, d.slab_bytes) == hipSuccess &&
               hipMemset(d.d_stats, 0, kStatsWords * sizeof(unsigned long long)) == hipSuccess && hipDeviceSynchronize() == hipSuccess &&
               static_scratch_setup(ordinal, &d.static_scratch) == hipSuccess;
     return ok ? SRT_OK : SRT_E_HIP;

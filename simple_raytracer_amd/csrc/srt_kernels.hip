@@ -64,6 +64,8 @@ hipError_t static_scratch_setup(int device, unsigned char** ptr)
 #define SRT_WAVES_PER_SIMD 3   // occupancy the register allocator is asked to make room for (measured: 2 -> 25.7 ms, 3 -> 21.1 ms, 4 -> 22.7 ms)
 #endif
 
+size_t trace_frame_slab_block_bytes();
+
 constexpr int kBlock = 256;
 constexpr int kWaves = kBlock / 64;
 constexpr uint32_t kChunk = 256;       // items drawn from the global counter at a time
@@ -869,9 +871,10 @@ static uint32_t resident_blocks(K kernel)
 }
 
 hipError_t launch_trace(const SceneView& sc, const RenderArgs& ra_in, bool exact, bool counted, float* d_samples,
-                        unsigned long long* d_stats, uint32_t* d_work_counter, float* d_timeline, void* d_frame_slab, hipStream_t stream, int walk_tune)
+                        unsigned long long* d_stats, uint32_t* d_work_counter, float* d_timeline, void* d_frame_slab, size_t slab_bytes, hipStream_t stream, int walk_tune)
 {
     if (ra_in.n_items == 0u) return hipSuccess;
+    if (slab_bytes < trace_frame_slab_block_bytes()) return hipErrorInvalidValue;
     if (d_frame_slab == nullptr || d_samples == nullptr || d_stats == nullptr || d_work_counter == nullptr) return hipErrorInvalidValue;
     q4* const slab = reinterpret_cast<q4*>(d_frame_slab);
     RenderArgs ra = ra_in;
@@ -907,6 +910,9 @@ hipError_t launch_trace(const SceneView& sc, const RenderArgs& ra_in, bool exact
     uint32_t blocks = (ra.n_items + kBlock - 1) / kBlock;
     if (blocks > fit) blocks = fit;
     if (blocks > max_blocks) blocks = max_blocks;
+    // every block of the grid owns a part of the frame slab: a smaller slab means a smaller grid
+    const size_t slab_blocks = slab_bytes / trace_frame_slab_block_bytes();
+    if ((size_t)blocks > slab_blocks) blocks = (uint32_t)slab_blocks;
     dim3 grid(blocks), block(kBlock);
     // Items per draw from the global counter: kChunk for big passes; a short pass gets smaller ranges (down to one
     // wavefront's worth), so that every wavefront draws several times and expensive screen regions are spread out.
@@ -968,7 +974,8 @@ hipError_t launch_trace(const SceneView& sc, const RenderArgs& ra_in, bool exact
 }
 
 // Every wavefront of the largest grid owns FRAME_SLOTS levels of 64 frames of 64 bytes.
-size_t trace_frame_slab_bytes() { return (size_t)kMaxBlocks * kWaves * FRAME_SLOTS * FRAME_SLAB_LEVEL_BYTES; }
+size_t trace_frame_slab_block_bytes() { return (size_t)kWaves * FRAME_SLOTS * FRAME_SLAB_LEVEL_BYTES; }
+size_t trace_frame_slab_bytes() { return (size_t)kMaxBlocks * trace_frame_slab_block_bytes(); }
 static_assert((unsigned long long)kMaxBlocks * kWaves * FRAME_SLOTS * FRAME_SLAB_LEVEL_BYTES < (1ull << 32), "frame offsets are 32-bit");
 size_t trace_timeline_records() { return (size_t)kMaxBlocks * kWaves; }
 size_t trace_timeline_offset() { return (size_t)1100 * kWaves * kTimelinePerWave * sizeof(float4); }

@@ -13,16 +13,19 @@ namespace srt {
 // d_stats: 56 x uint64 the kernel adds to: rays_path, rays_shadow, hit_nodes, box_tests, sphere_tests,
 // tri_tests, rect_tests, section counts, alarm; [16, 32) cycles per part, [32, 48) the same weighted by active lanes, 48 shadow queries answered without a traversal.  d_work_counter: one uint32, reset by the launcher on `stream`.
 // d_timeline: trace_timeline_bytes() of device memory; only -DSRT_TIMELINE builds write to it (per-wavefront clock records).
-// d_frame_slab: trace_frame_slab_bytes() of device memory, where the wavefronts keep the frames of pending ray-tree nodes
-// that do not fit their LDS; contents need not survive a launch, and launches that overlap must not share it.
+// d_frame_slab: slab_bytes of device memory, where the wavefronts keep the frames of pending ray-tree nodes that do not
+// fit their LDS: trace_frame_slab_block_bytes() per block of the persistent grid, trace_frame_slab_bytes() for the largest
+// grid the kernels ever use; with less, the grid shrinks to the blocks the slab has room for (at least one).  Contents
+// need not survive a launch, and launches that overlap must not share it.
 // walk_tune (scenes whose tree is walked with a stack): which traversal quantum the kernel uses -- long, short, or
 // "measure both at the start of the launch and take the faster".  A calibrating launch adds what it measured to d_stats
 // words 12-15 (traversals finished, wall-clock ticks; preset 0 then 1); walk_tune_prefers_short() reads them.
 enum { WALK_TUNE_LONG = 0, WALK_TUNE_SHORT = 1, WALK_TUNE_CALIBRATE = 2 };
 hipError_t launch_trace(const SceneView& sc, const RenderArgs& ra, bool exact, bool counted, float* d_samples,
-                        unsigned long long* d_stats, uint32_t* d_work_counter, float* d_timeline, void* d_frame_slab, hipStream_t stream,
+                        unsigned long long* d_stats, uint32_t* d_work_counter, float* d_timeline, void* d_frame_slab, size_t slab_bytes, hipStream_t stream,
                         int walk_tune = WALK_TUNE_LONG);
 size_t trace_frame_slab_bytes();
+size_t trace_frame_slab_block_bytes();
 // The decision rule, shared by the kernel and the host: short quanta must finish traversals at least 3 % faster.
 SRT_HD bool walk_tune_prefers_short(double done_long, double ticks_long, double done_short, double ticks_short)
 {

@@ -14,12 +14,16 @@ and the copy of the frame to the host.  The scene, camera and buffers are reside
   c5            the 983,040-triangle mesh, 7680x4320, 1024 spp, depth 8
   (--spp / --size shrink c3..c5 for quick runs; the workload string then says so.)
 
-Several GPUs, weak scaling (the configuration's spp per GPU, N times that per frame):
+Several GPUs (--scaling weak|strong; default: weak for c1..c3, strong for c4 and c5, whose configurations name one
+fixed frame over 2 / 4 / 8 GPUs).  weak: the configuration's spp per GPU, N times that per frame.  strong: the
+configuration's own frame, its tiles shared out over the N GPUs.
   * started as a plain command (`python bench.py --gpus N`), one process drives all N GPUs through one libsrt context:
     32x32 screen tiles interleaved over the devices, tile buffers gathered on the first device by grouped
     ncclSend / ncclRecv, assembled there;
   * started by torch.distributed.run with N ranks, every rank owns one GPU and one context, and the tile buffers are
     gathered on rank 0 with torch.distributed (backend nccl = RCCL), then assembled by srt_assemble_tiles.
+Either way the line reports, per step: gather_ms and assemble_ms (HIP events), the device time of every GPU's kernels,
+and the tail (slowest minus median GPU).
 
 Metric: Mrays/s, rays = GetRayColor calls with depth >= 1 (primary + bounce rays, one closest-hit query each), counted
 on the device.  Prints one JSON line on rank 0.
@@ -42,8 +46,10 @@ import simple_raytracer_amd as srt  # noqa: E402
 from simple_raytracer_amd import game1, scenes  # noqa: E402
 
 TILE = 32
-PEAK_FP32_TFLOPS = 157.3   # MI355X vector FP32 (= f32 MFMA) peak
+PEAK_FP32_TFLOPS = 157.3   # MI355X vector FP32 (= f32 MFMA) peak; it counts a packed fused multiply-add, 4 flops per lane and cycle
+PEAK_FP32_UNFUSED_TFLOPS = PEAK_FP32_TFLOPS / 4.0   # one unfused, unpacked operation per lane and cycle: what this arithmetic may use
 PEAK_HBM_GBS = 8000.0      # MI355X HBM3E peak
+PEAK_L2_GBS = 34500.0      # aggregate L2 bandwidth (8 XCDs)
 
 # name -> (scene factory(width, height), world kind, width, height, spp per GPU, depth, description)
 CONFIGS = {
@@ -59,14 +65,12 @@ CONFIGS = {
            "983,040-triangle mesh, 2 point lights, surfacelist world (library tree)"),
 }
 
-# Memory-side bytes per launch of the dominant kernel on the N=1 workload, from separate `rocprofv3 --pmc FETCH_SIZE`
-# and `--pmc WRITE_SIZE` passes over this command (tools/pmc_traffic.sh; the counters are in KiB, and FETCH_SIZE is
-# doubled, the correction for gfx950).  They are not re-measured by a normal run: a counter pass needs the profiler.
-# config -> (FETCH_SIZE KiB, WRITE_SIZE KiB, the profile the numbers come from)
-MEASURED_TRAFFIC_KIB = {
-    "c2": (3.909e5, 3.330e6, "profiles/r2c_c2_pmc_and_kernel_stats.txt"),   # trace_kernel<true,false,true>
-    "c3": (6.289e6, 7.314e6, "profiles/r2c_c3_pmc_and_kernel_stats.txt"),   # mesh_trace_kernel<false,false>
-}
+# Memory-side numbers of the dominant kernel on the N=1 workloads come from counter passes of this same command
+# (tools/pmc_bench.sh: separate `rocprofv3 --pmc` runs for FETCH_SIZE, WRITE_SIZE and the L2 request / hit / miss counters;
+# FETCH_SIZE and WRITE_SIZE are in KiB, and FETCH_SIZE is doubled, the correction for gfx950).  A normal run has no
+# profiler attached, so it reads the digest of those passes (tools/pmc_bench_digest.py writes it): per configuration the
+# bytes per frame and the L2 request rate, with the profile they come from.
+TRAFFIC_DIGEST = os.path.join(ROOT, "profiles", "r3_traffic_digest.json")
 
 # Algorithmic work per event: bytes fetched / FP32 operations (add, sub, mul, div, sqrt, min, max, compare = 1 each)
 # of the reference algorithm, excluding work the GPU legitimately skips.
@@ -125,7 +129,13 @@ def cpu_baseline(name, world, lights, cam, width, height, spp, depth):
             _, st = sc.render(ocam, width, height, samples=1, max_depth=depth, seed=1, window=(x0, y0, x0 + cols, y0 + rows), threads=threads)
         sample = "%dx%d window at the centre of the %dx%d frame, 1 spp, depth %d, the reference's own tree (built in %.1f s): %d rays in %.1f s" % (
             cols, rows, width, height, depth, build_s, st["rays_path"], st["seconds"])
-    return {"value": round(st["rays_path"] / st["seconds"] / 1e6, 6), "unit": "Mrays/s", "cores": threads, "kind": "port", "sample": sample}
+    out = {"value": round(st["rays_path"] / st["seconds"] / 1e6, 6), "unit": "Mrays/s", "cores": threads, "kind": "port", "sample": sample,
+           "rays_in_sample": int(st["rays_path"])}
+    if st["rays_path"] < 1000:
+        # the reference's tree costs 10^4..10^5 box tests per ray on these scenes: a bounded sample holds few rays, and a
+        # rate from so few says how slow that tree is, nothing about the GPU kernels
+        out["unit"] = "Mrays/s (from only %d rays: an order of magnitude, not a measurement)" % st["rays_path"]
+    return out
 
 
 def pinned_frame(pixels):
@@ -145,7 +155,10 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--gather", choices=["rccl", "peer"], default="rccl", help="in-library multi-GPU: how tiles reach the first device")
     ap.add_argument("--virtual-devices", action="store_true", help="rehearsal: all --gpus entries name device 0 (one context, several replicas)")
+    ap.add_argument("--scaling", choices=["weak", "strong"], default="", help="several GPUs: weak = the configuration's spp per GPU, "
+                    "strong = the configuration's own frame over all GPUs (default: strong for c4 and c5, weak otherwise)")
     args = ap.parse_args()
+    scaling = args.scaling or ("strong" if args.config in ("c4", "c5") else "weak")
 
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -164,7 +177,7 @@ def main():
     if args.size:
         width, height = (int(v) for v in args.size.lower().split("x"))
         reduced.append("size")
-    spp = spp_per_gpu * n_gpus
+    spp = spp_per_gpu * n_gpus if scaling == "weak" else spp_per_gpu
 
     # SRT_BENCH_BACKEND=gloo is a rehearsal mode for boxes with fewer GPUs than ranks (the ranks then share devices and
     # the tile buffers are gathered through host memory); the measured configuration is nccl = RCCL, one GPU per rank.
@@ -206,6 +219,7 @@ def main():
     import ctypes as C
     device_ms = []     # per step: device time of the frame's trace + resolve kernels (HIP events on the launch stream)
     counts = [0.0, 0.0]  # path rays, shadow rays of the timed steps
+    gather_ms, assemble_ms, per_device = [], [], []   # several GPUs, per step (in-library) or from one extra step (one process per GPU)
 
     def step(record=False):
         if tf is None:
@@ -216,6 +230,10 @@ def main():
                 device_ms.append(st["kernel_ms"])
                 counts[0] += st["rays_path"]
                 counts[1] += st["rays_shadow"]
+                if in_library:
+                    gather_ms.append(st["gather_ms"])
+                    assemble_ms.append(st["assemble_ms"])
+                    per_device.append([r.device_stats(i)["kernel_ms"] for i in range(len(info["devices"]))])
         else:
             tf.render_local()
             tf.gather()      # RCCL gather of the tile buffers to rank 0
@@ -244,7 +262,26 @@ def main():
         st = r.stats()     # counters accumulated over the timed launches; kernel_ms is the last launch's
         rays, shadow = float(st["rays_path"]), float(st["rays_shadow"])
         device_ms.append(st["kernel_ms"])
-    per_device_ms = [round(r.device_stats(i)["kernel_ms"], 4) for i in range(len(info["devices"]))] if in_library else None
+        # the parts of a step, from one more (untimed) step with HIP events around them on this rank's stream
+        fence()
+        r.stats()
+        ev = [torch.cuda.Event(enable_timing=True) for _ in range(3)]
+        tf.render_local()
+        k_ms = r.stats()["kernel_ms"]            # waits for this rank's kernels
+        if world > 1:
+            dist.barrier()                       # every rank has its tiles: what follows is the exchange alone
+        ev[0].record()
+        tf.gather()
+        ev[1].record()
+        frame = tf.assemble()
+        ev[2].record()
+        torch.cuda.synchronize()
+        parts = torch.tensor([k_ms, ev[0].elapsed_time(ev[1]), ev[1].elapsed_time(ev[2])], dtype=torch.float64, device=reduce_device)
+        every = [torch.zeros_like(parts) for _ in range(world)]
+        dist.all_gather(every, parts)
+        per_device.append([float(e[0].item()) for e in every])
+        gather_ms.append(float(every[0][1].item()))      # rank 0 receives
+        assemble_ms.append(float(every[0][2].item()))
 
     t = torch.tensor([elapsed], dtype=torch.float64, device=reduce_device)
     rr = torch.tensor([rays, shadow], dtype=torch.float64, device=reduce_device)
@@ -278,18 +315,43 @@ def main():
         # show VALU issue ~ 96 % busy and 0.3 TB/s from beyond L2, so vector FP32 issue is their roof as well, and
         # the node / triangle bytes are reported against the L2 bandwidth as a second figure.
         roofline = {"bound": "valu_fp32", "achieved": round(tflops, 3), "peak": PEAK_FP32_TFLOPS, "unit": "TFLOP/s",
-                    "frac": round(tflops / PEAK_FP32_TFLOPS, 4)}
-        traffic, traffic_source = None, None
-        if world == 1 and not in_library and not reduced and args.config in MEASURED_TRAFFIC_KIB:
-            fetch_kib, write_kib, where = MEASURED_TRAFFIC_KIB[args.config]
-            traffic = int((2.0 * fetch_kib + write_kib) * 1024)
-            traffic_source = "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command, 2*FETCH+WRITE (%s); constant, not re-measured in this run" % where
+                    "frac": round(tflops / PEAK_FP32_TFLOPS, 4),
+                    # the peak counts packed fused multiply-adds (4 flops per lane and cycle); this arithmetic may not contract
+                    # a * b + c and mostly cannot pack, so one operation per lane and cycle is the most it could ever issue
+                    "peak_unfused": PEAK_FP32_UNFUSED_TFLOPS, "frac_unfused": round(tflops / PEAK_FP32_UNFUSED_TFLOPS, 4)}
+        # memory side, from the counter passes of this command (a constant: a normal run has no profiler attached)
+        traffic, traffic_source, memory = None, None, {}
+        if world == 1 and not in_library and not reduced and os.path.exists(TRAFFIC_DIGEST):
+            d = json.load(open(TRAFFIC_DIGEST)).get(args.config)
+            if d:
+                traffic = int((2.0 * d["fetch_kib"] + d["write_kib"]) * 1024)
+                traffic_source = ("rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command, 2*FETCH+WRITE summed over the %d kernel launches of a frame (%s); "
+                                  "constant, not re-measured in this run" % (d["launches_per_frame"], d["source"]))
+                memory = {"hbm_side_gbs": round(traffic / (avg_ms * 1e-3) / 1e9, 1),
+                          "hbm_side_frac": round(traffic / (avg_ms * 1e-3) / 1e9 / PEAK_HBM_GBS, 4),
+                          "l2_request_gbs": round(d["tcc_req"] * 128.0 / (avg_ms * 1e-3) / 1e9, 1),
+                          "l2_frac": round(d["tcc_req"] * 128.0 / (avg_ms * 1e-3) / 1e9 / PEAK_L2_GBS, 4),
+                          "l2_hit_rate": round(d["tcc_hit"] / max(1.0, d["tcc_hit"] + d["tcc_miss"]), 3)}
         kernel = "trace_kernel" if args.config in ("c1", "c2") else "mesh_trace_kernel"
         roofline.update({"traffic": traffic, "traffic_source": traffic_source, "kernel": kernel + " (+ resolve_kernel) of one frame",
                          "avg_launch_ms": round(avg_ms, 4),
                          "algorithmic_flops_per_launch": aflops, "algorithmic_bytes_per_launch": abytes,
-                         "algorithmic_gbs": round(gbs, 2), "algorithmic_tflops": round(tflops, 3),
-                         "counted_spp": count_spp})
+                         "algorithmic_tflops": round(tflops, 3), "counted_spp": count_spp})
+        roofline.update(memory)
+        # the algorithmic bytes (nodes, primitives, hit records) are served by the scalar cache, L1 and L2, not by HBM: above the
+        # HBM peak the figure can only be a cache-level rate, and it is named so
+        roofline["algorithmic_cache_level_gbs" if gbs > PEAK_HBM_GBS or args.config in ("c1", "c2") else "algorithmic_gbs"] = round(gbs, 2)
+        multi = None
+        if n_gpus > 1 and per_device:
+            pd = np.array(per_device, dtype=np.float64)          # steps x devices
+            mean_pd = pd.mean(axis=0)
+            multi = {"scaling": scaling, "rccl_ranks": info["rccl_ranks"] if in_library else (world if world > 1 and backend == "nccl" else 0),
+                     "gather_ms": round(float(np.mean(gather_ms)), 4), "assemble_ms": round(float(np.mean(assemble_ms)), 4),
+                     "per_device_kernel_ms": [round(float(v), 4) for v in mean_pd],
+                     "tail_ms": round(float(np.mean(pd.max(axis=1) - np.median(pd, axis=1))), 4),
+                     "measured_over": "the timed steps" if in_library else "one more step after the timed ones (a barrier before the exchange)",
+                     "gather_ms_is": ("from the end of the first device's own tiles to the arrival of all tiles there: transfers + the wait for the slowest device"
+                                      if in_library else ("the %s gather to rank 0 after a barrier: transfers alone" % ("RCCL" if backend == "nccl" else "gloo (through host memory)")))}
         how = ("single frame buffer" if n_gpus == 1 else
                ("one process, one context over %d devices %s: 32x32 tiles interleaved, %s, assembled on device %d" % (
                    n_gpus, info["devices"], "grouped ncclSend/ncclRecv (communicator of %d ranks)" % info["rccl_ranks"] if info["gather"] == srt.GATHER_RCCL
@@ -301,9 +363,10 @@ def main():
             "metric": "Mrays/sec (primary+bounce)", "value": round(total_rays / elapsed / 1e6, 2), "unit": "Mrays/s",
             "n_gpus": n_gpus, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_step, 4),
             "ms_per_step_device_only": round(avg_ms, 4),
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "config": {"workload": "%s: %s, %dx%d, %d spp per GPU (%d total), depth %d; %s; the step ends with the frame in pinned host memory%s" % (
-                           args.config, what, width, height, spp_per_gpu, spp, depth, how,
+            "higher_is_better": True, "scaling": scaling, "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": "%s: %s, %dx%d, %s, depth %d; %s; the step ends with the frame in pinned host memory%s" % (
+                           args.config, what, width, height,
+                           ("%d spp per GPU (%d total)" % (spp_per_gpu, spp)) if scaling == "weak" else ("%d spp, one frame shared out over the GPUs" % spp), depth, how,
                            "; REDUCED %s against the named configuration" % "+".join(reduced) if reduced else ""),
                        "name": args.config, "width": width, "height": height, "spp": spp, "max_depth": depth, "seed": 1,
                        "devices": info["devices"] if in_library else [device_index], "rccl_ranks": info["rccl_ranks"] if in_library else (world if world > 1 and backend == "nccl" else 0),
@@ -314,8 +377,8 @@ def main():
             "traversals_per_sec_M": round((total_rays + total_shadow) / elapsed / 1e6, 2),
             "roofline": roofline,
         }
-        if per_device_ms is not None:
-            line["per_device_kernel_ms_last_step"] = per_device_ms
+        if multi is not None:
+            line["multi_gpu"] = multi
         if n_gpus == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(args.config, scene_world, lights, cam, width, height, spp, depth)
         print(json.dumps(line), flush=True)

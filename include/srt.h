@@ -92,7 +92,8 @@ enum {
 
 /* The devices of a context.  The reference fans one render out over Environment.ProcessorCount threads inside one
  * process (Game1.cs:89-92, 161-167); a context fans it out over the listed GPUs the same way, inside the library:
- * every device holds the whole scene, traces the 32x32 screen tiles t with t % n_devices == its position in the list,
+ * every device holds the whole scene, traces the 32x32 screen tiles t with t % n_devices == its position in the list
+ * (tile numbering: srt_render_params),
  * and hands them to the first device, which assembles the frame.
  *   n_devices == 0                    one device: `device` (callers that only know the first two fields keep working)
  *   n_devices == SRT_ALL_DEVICES      every visible device, in ordinal order
@@ -129,10 +130,12 @@ typedef struct {
     int32_t  mode;           /* SRT_MODE_* */
     int32_t  layout;         /* SRT_LAYOUT_* */
     int32_t  tile_w, tile_h; /* screen tile, multiples of 8; 0 = 32.  Only used with SRT_LAYOUT_TILES. */
-    int32_t  rank, world_size; /* tile t (row-major over the tile grid) belongs to rank t % world_size;
-                                  a rank's j-th tile (j = t / world_size) occupies pixels
-                                  [j*tile_w*tile_h, (j+1)*tile_w*tile_h) of its buffer, row-major inside the tile,
-                                  edge tiles padded.  world_size 0 or 1 = everything. */
+    int32_t  rank, world_size; /* tile t belongs to rank t % world_size.  Tiles are numbered row by row over the tile
+                                  grid (tiles_x = ceil(width / tile_w) columns), starting ty columns in in row ty: tile t is
+                                  in row ty = t / tiles_x, column (t % tiles_x + ty) % tiles_x, so that the ranks lie on
+                                  diagonals of the grid whatever tiles_x is.  A rank's j-th tile (j = t / world_size)
+                                  occupies pixels [j*tile_w*tile_h, (j+1)*tile_w*tile_h) of its buffer, row-major inside
+                                  the tile, edge tiles padded.  world_size 0 or 1 = everything. */
 } srt_render_params;
 
 typedef struct {
@@ -170,6 +173,11 @@ typedef struct {
        PointLight.calculateLight is finite: with NdotL = 0 (RaytracingClasses.cs:113) the diffuse and the specular term
        (:160-161, :185) are zero whatever the ray meets, so the result is the reference's bit for bit. */
     uint64_t shadow_unasked;
+    /* Contexts with several devices, last frame (0 otherwise), from HIP events on the first device's stream:
+       gather_ms    from the end of the first device's own tiles to the arrival of every other device's tiles there --
+                    the transfers and the wait for the slowest device;
+       assemble_ms  the kernel that puts the gathered tiles into the row-major frame. */
+    double   gather_ms, assemble_ms;
 } srt_stats;
 
 typedef struct srt_ctx srt_ctx;

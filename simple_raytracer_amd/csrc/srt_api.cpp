@@ -121,6 +121,8 @@ struct srt_ctx {
     size_t gathered_capacity = 0;         // pixels
     uint32_t* d_frame = nullptr;          // several devices: the assembled row-major frame
     size_t frame_capacity = 0;
+    hipEvent_t ev_own_tiles = nullptr, ev_gathered = nullptr, ev_assembled = nullptr;   // several devices: marks on dev[0]'s stream
+    bool multi_pending = false;           // the marks of a frame have not been read yet
     uint32_t* d_mix = nullptr;            // one buffer of the mix-buffer technique
     size_t mix_capacity = 0;              // in pixels
     uint32_t* d_post[2] = {nullptr, nullptr};   // the picture before / after a pass of a post-process filter
@@ -240,6 +242,15 @@ int collect_stats(srt_ctx* c)
         p.kernel_ms = ms;
         d.stats_pending = false;
         alarm = alarm || s[11] != 0ull;
+    }
+    if (c->multi_pending) {
+        SRT_HIP(c, hipSetDevice(c->dev[0].device));
+        SRT_HIP(c, hipEventSynchronize(c->ev_assembled));
+        float g = 0.0f, a = 0.0f;
+        SRT_HIP(c, hipEventElapsedTime(&g, c->ev_own_tiles, c->ev_gathered));
+        SRT_HIP(c, hipEventElapsedTime(&a, c->ev_gathered, c->ev_assembled));
+        c->stats.gather_ms = g; c->stats.assemble_ms = a;
+        c->multi_pending = false;
     }
     zero_counts(c->stats);
     for (DeviceState& d : c->dev) {
@@ -444,6 +455,17 @@ struct HipDevices {
     int gather(const MultiPlan& plan)
     {
         DeviceState& root = c->dev[0];
+        SRT_HIP(c, hipSetDevice(root.device));
+        SRT_HIP(c, hipEventRecord(c->ev_own_tiles, root.stream));
+        int rc = gather_tiles(plan);
+        if (rc != SRT_OK) return rc;
+        SRT_HIP(c, hipSetDevice(root.device));
+        SRT_HIP(c, hipEventRecord(c->ev_gathered, root.stream));
+        return SRT_OK;
+    }
+    int gather_tiles(const MultiPlan& plan)
+    {
+        DeviceState& root = c->dev[0];
         if (c->gather == SRT_GATHER_RCCL) {
             // every peer has its own xGMI link to the first device: (n - 1) receives there, one send on each peer
             SRT_NCCL(c, g_rccl.GroupStart());
@@ -478,6 +500,8 @@ struct HipDevices {
         SRT_HIP(c, hipSetDevice(root.device));
         hipError_t e = launch_assemble(plan.assemble, c->d_gathered, (size_t)plan.stride, c->d_frame, root.stream);
         if (e != hipSuccess) return hip_fail(c, e, "assemble kernel launch");
+        SRT_HIP(c, hipEventRecord(c->ev_assembled, root.stream));
+        c->multi_pending = true;
         return SRT_OK;
     }
 };
@@ -618,6 +642,11 @@ int srt_create(const srt_config* cfg, srt_ctx** out)
     // which exercises loading librccl, ncclCommInitAll and the rank count check; there is still nothing to gather
     if (ordinals.size() == 1 && n_cfg != 0 && gather == SRT_GATHER_RCCL && std::getenv("SRT_RCCL_SINGLE")) c->gather = SRT_GATHER_RCCL;
     if (ordinals.size() > 1) {
+        hipSetDevice(ordinals[0]);
+        if (hipEventCreate(&c->ev_own_tiles) != hipSuccess || hipEventCreate(&c->ev_gathered) != hipSuccess || hipEventCreate(&c->ev_assembled) != hipSuccess) {
+            srt_destroy(c);
+            return fail(nullptr, SRT_E_HIP, "could not create the events of the gather");
+        }
         // direct xGMI access between the first device and the others, where the platform offers it
         for (size_t i = 1; i < ordinals.size(); i++) {
             if (ordinals[i] == ordinals[0]) continue;
@@ -669,6 +698,7 @@ void srt_destroy(srt_ctx* c)
         if (c->d_post_progress) hipFree(c->d_post_progress);
         if (c->h_pinned) hipHostFree(c->h_pinned);
         for (hipEvent_t e : c->pass_done) if (e) hipEventDestroy(e);
+        for (hipEvent_t e : {c->ev_own_tiles, c->ev_gathered, c->ev_assembled}) if (e) hipEventDestroy(e);
     }
     for (DeviceState& d : c->dev) destroy_device(d);
     delete c;

@@ -904,6 +904,21 @@ SRT_HD uint32_t mix_colors(uint32_t a, uint32_t b)
     return pack_color(m.x, m.y, m.z);
 }
 
+// Tiles are numbered row by row, and inside row ty the numbering starts ty columns in: tile t sits in row
+// ty = t / tiles_x at column (t % tiles_x + ty) % tiles_x.  With tile t going to rank t % world_size the ranks then lie
+// on diagonals of the tile grid even when tiles_x is a multiple of world_size (3840 and 7680 pixels are 120 and 240
+// tiles of 32: 2, 4 and 8 ranks would otherwise own the same columns in every row).
+SRT_HD void tile_position(const RenderArgs& ra, uint32_t t, uint32_t& tx, uint32_t& ty)
+{
+    ty = t / (uint32_t)ra.tiles_x;
+    tx = (t - ty * (uint32_t)ra.tiles_x + ty) % (uint32_t)ra.tiles_x;
+}
+SRT_HD uint32_t tile_number(const RenderArgs& ra, uint32_t tx, uint32_t ty)
+{
+    const uint32_t n = (uint32_t)ra.tiles_x;
+    return ty * n + (tx + n - ty % n) % n;
+}
+
 // Maps a pixel slot of this rank to its pixel.  Slots enumerate this rank's tiles (tile t belongs to
 // rank t % world_size), and inside a tile 8x8 blocks, so that 64 consecutive slots are an 8x8
 // pixel block.  Returns false for padding pixels of edge tiles.
@@ -912,7 +927,8 @@ SRT_HD bool work_to_pixel(const RenderArgs& ra, uint32_t w, int32_t& x, int32_t&
     uint32_t tile_px = (uint32_t)(ra.tile_w * ra.tile_h);
     uint32_t j = w / tile_px, rem = w - j * tile_px;
     uint32_t t = j * (uint32_t)ra.world_size + (uint32_t)ra.rank;
-    uint32_t ty = t / (uint32_t)ra.tiles_x, tx = t - ty * (uint32_t)ra.tiles_x;
+    uint32_t tx, ty;
+    tile_position(ra, t, tx, ty);
     uint32_t sbw = (uint32_t)ra.tile_w >> 3;
     uint32_t sb = rem >> 6, k = rem & 63u;
     uint32_t sby = sb / sbw, sbx = sb - sby * sbw;
@@ -924,14 +940,14 @@ SRT_HD bool work_to_pixel(const RenderArgs& ra, uint32_t w, int32_t& x, int32_t&
 }
 
 // Where pixel i = x + y * width of the frame sits in the gathered tile buffers of a partitioned render (rank r's buffer
-// starts at r * stride): tile t = tx + ty * tiles_x belongs to rank t % world_size, which holds it as its (t / world_size)-th
+// starts at r * stride): its tile, number t, belongs to rank t % world_size, which holds it as its (t / world_size)-th
 // tile, row-major inside the tile.  The inverse of work_to_pixel's SRT_LAYOUT_TILES output index.
 SRT_HD size_t gathered_index(const RenderArgs& ra, uint32_t i, size_t stride)
 {
     uint32_t y = i / (uint32_t)ra.width, x = i - y * (uint32_t)ra.width;
     uint32_t tx = x / (uint32_t)ra.tile_w, ty = y / (uint32_t)ra.tile_h;
     uint32_t lx = x - tx * (uint32_t)ra.tile_w, ly = y - ty * (uint32_t)ra.tile_h;
-    uint32_t t = tx + ty * (uint32_t)ra.tiles_x;
+    uint32_t t = tile_number(ra, tx, ty);
     uint32_t r = t % (uint32_t)ra.world_size, j = t / (uint32_t)ra.world_size;
     return (size_t)r * stride + (size_t)j * (uint32_t)(ra.tile_w * ra.tile_h) + ly * (uint32_t)ra.tile_w + lx;
 }

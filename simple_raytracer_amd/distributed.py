@@ -17,6 +17,18 @@ def tile_grid(width, height, tile_w, tile_h):
     return (width + tile_w - 1) // tile_w, (height + tile_h - 1) // tile_h
 
 
+def tile_position(t, tiles_x):
+    """(row, column) of tile number t: rows are numbered from a start that moves one column per row, so that
+    "tile t belongs to rank t % world_size" puts the ranks on diagonals of the grid (srt_render_params in srt.h)."""
+    row = t // tiles_x
+    return row, (t % tiles_x + row) % tiles_x
+
+
+def tile_number(col, row, tiles_x):
+    """Number of the tile at (column, row): the inverse of tile_position."""
+    return row * tiles_x + (col - row) % tiles_x
+
+
 def local_tile_ids(width, height, tile_w, tile_h, rank, world_size):
     """Global ids of the tiles a rank renders, in the order they sit in its buffer."""
     tx, ty = tile_grid(width, height, tile_w, tile_h)
@@ -32,7 +44,8 @@ def assemble_tiles_host(gathered, width, height, tile_w, tile_h, world_size):
     area = tile_w * tile_h
     for r in range(world_size):
         for j, t in enumerate(local_tile_ids(width, height, tile_w, tile_h, r, world_size)):
-            y0, x0 = (t // tx) * tile_h, (t % tx) * tile_w
+            row, col = tile_position(t, tx)
+            y0, x0 = row * tile_h, col * tile_w
             hh, ww = min(tile_h, height - y0), min(tile_w, width - x0)
             frame[y0:y0 + hh, x0:x0 + ww] = gathered[r, j * area:(j + 1) * area].reshape(tile_h, tile_w)[:hh, :ww]
     return frame

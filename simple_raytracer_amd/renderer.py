@@ -199,6 +199,7 @@ class Renderer:
         out["section_cycles"] = list(st.section_cycles)
         out["section_lane_cycles"] = list(st.section_lane_cycles)
         out["shadow_unasked"] = int(st.shadow_unasked)
+        out["gather_ms"], out["assemble_ms"] = float(st.gather_ms), float(st.assemble_ms)
         return out
 
     def stats(self):

@@ -6,6 +6,7 @@ import numpy as np
 
 import helpers
 import simple_raytracer_amd as srt
+from simple_raytracer_amd.distributed import tile_number
 from simple_raytracer_amd import game1, scenes
 from simple_raytracer_amd.raytracing import Material, Sphere
 
@@ -72,7 +73,7 @@ def scene_window(renderer, orc, make, n_surfaces, size=(640, 360), depth=4, samp
     tiles_x, tiles_y = (w + 31) // 32, (h + 31) // 32
     # the window's tile alone: "rank t of as many ranks as there are tiles"
     tile = renderer.render(w, h, samples=samples, max_depth=depth, seed=seed, layout=srt.LAYOUT_TILES, tile_w=32, tile_h=32,
-                           rank=tile_y * tiles_x + tile_x, world_size=tiles_x * tiles_y).reshape(32, 32)
+                           rank=tile_number(tile_x, tile_y, tiles_x), world_size=tiles_x * tiles_y).reshape(32, 32)
     lsb, npx = helpers.max_lsb_diff(tile[:rows, :], ref[y0:y0 + rows, x0:x0 + 32])
     return lsb, npx, len(np.unique(tile[:rows, :])), nodes, renderer.stats(), ost
 

@@ -125,7 +125,8 @@ def tiles_roundtrip(renderer, oracle, world_size=3, tile=(16, 8)):
         n_local = len(range(rank, tiles_x * tiles_y, world_size))
         assert buf.shape == (n_local * tw * th,)
         for j, t in enumerate(range(rank, tiles_x * tiles_y, world_size)):
-            ty, tx = divmod(t, tiles_x)
+            ty = t // tiles_x                      # tile numbering of srt_render_params: row ty starts ty columns in
+            tx = (t % tiles_x + ty) % tiles_x
             tile_px = buf[j * tw * th:(j + 1) * tw * th].reshape(th, tw)
             y0, x0 = ty * th, tx * tw
             hh, ww = min(th, h - y0), min(tw, w - x0)

@@ -70,9 +70,30 @@ def test_assemble_tiles_host_inverts_the_layout():
     gathered = np.zeros((world, stride), dtype=np.uint32)
     for r in range(world):
         for j, t in enumerate(D.local_tile_ids(w, h, tw, th, r, world)):
-            y0, x0 = (t // tx) * th, (t % tx) * tw
+            row, col = D.tile_position(t, tx)
+            y0, x0 = row * th, col * tw
             tile = np.zeros((th, tw), dtype=np.uint32)
             hh, ww = min(th, h - y0), min(tw, w - x0)
             tile[:hh, :ww] = frame[y0:y0 + hh, x0:x0 + ww]
             gathered[r, j * tw * th:(j + 1) * tw * th] = tile.reshape(-1)
     assert (D.assemble_tiles_host(gathered, w, h, tw, th, world) == frame).all()
+
+
+def test_tile_numbering_puts_ranks_on_diagonals():
+    """tiles_x a multiple of the rank count (3840 pixels = 120 tiles of 32 over 2, 4 or 8 ranks) must not hand every rank
+    the same columns in every row: with the numbering of srt_render_params a rank's tiles move one column per row."""
+    tiles_x, tiles_y = 120, 68
+    for world in (2, 4, 8):
+        owner = np.empty((tiles_y, tiles_x), dtype=np.int64)
+        for t in range(tiles_x * tiles_y):
+            row, col = D.tile_position(t, tiles_x)
+            assert D.tile_number(col, row, tiles_x) == t
+            owner[row, col] = t % world
+        for r in range(world):
+            cols_per_row = [set(np.nonzero(owner[row] == r)[0] % world) for row in range(world)]
+            assert len(set(map(frozenset, cols_per_row))) == world      # a different set of columns in each of `world` rows
+            share = (owner == r).mean()
+            assert abs(share - 1.0 / world) < 1e-3
+        # every block of world x world tiles holds every rank in every row and every column
+        block = owner[:world, :world]
+        assert all(len(set(block[i])) == world and len(set(block[:, i])) == world for i in range(world))

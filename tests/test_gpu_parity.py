@@ -9,6 +9,7 @@ import helpers
 import mesh_cases
 import parity_cases
 import simple_raytracer_amd as srt
+from simple_raytracer_amd.distributed import tile_position
 from golden.make_golden import GOLDEN
 
 pytestmark = pytest.mark.gpu
@@ -158,7 +159,7 @@ def test_gpu_full_size_window_parity_and_invariants(gpu, oracle):
         buf = gpu.render(w, h, samples=16, max_depth=8, seed=1, layout=srt.LAYOUT_TILES, tile_w=tw, tile_h=th, rank=rank, world_size=2)
         total_rays += gpu.stats()["rays_path"]
         for j, t in enumerate(range(rank, tiles_x * tiles_y, 2)):
-            ty, tx = divmod(t, tiles_x)
+            ty, tx = tile_position(t, tiles_x)
             y0, x0 = ty * th, tx * tw
             hh, ww = min(th, h - y0), min(tw, w - x0)
             frame[y0:y0 + hh, x0:x0 + ww] = buf[j * tw * th:(j + 1) * tw * th].reshape(th, tw)[:hh, :ww]

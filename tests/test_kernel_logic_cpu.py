@@ -7,6 +7,7 @@ import pytest
 
 import parity_cases
 import simple_raytracer_amd as srt
+from simple_raytracer_amd.distributed import tile_position
 
 
 @pytest.fixture(scope="module")
@@ -145,7 +146,7 @@ def test_item_order_covers_every_pixel_and_sample_once(emu, width, height, sampl
         tiles_x, tiles_y = (width + 31) // 32, (height + 31) // 32
         mine = 0
         for t in range(rank, tiles_x * tiles_y, world):
-            tx, ty = t % tiles_x, t // tiles_x
+            ty, tx = tile_position(t, tiles_x)
             mine += (min(32, width - tx * 32)) * (min(32, height - ty * 32))
         assert len(pairs) == mine * samples
 

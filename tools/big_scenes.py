@@ -20,6 +20,7 @@ import numpy as np  # noqa: E402
 
 import simple_raytracer_amd as srt  # noqa: E402
 from simple_raytracer_amd import scenes  # noqa: E402
+from simple_raytracer_amd.distributed import tile_number  # noqa: E402
 
 W, H = 1920, 1080
 CONFIGS = {
@@ -91,7 +92,7 @@ def main():
             # "rank tile_id of tiles_x*tiles_y ranks")
             tiles_x, tiles_y = (W + 31) // 32, (H + 31) // 32
             g = r.render(W, H, samples=1, max_depth=depth, seed=1, layout=srt.LAYOUT_TILES, tile_w=32, tile_h=32,
-                         rank=tile_y * tiles_x + tile_x, world_size=tiles_x * tiles_y).reshape(32, 32)
+                         rank=tile_number(tile_x, tile_y, tiles_x), world_size=tiles_x * tiles_y).reshape(32, 32)
             x0, y0, x1, y1 = win
             lsb, npx = helpers.max_lsb_diff(g[:8, :], ref[y0:y1, x0:x1])
             line.update({"bvhnode_window_max_lsb": lsb, "bvhnode_window_diff_pixels": npx, "bvhnode_1spp_kernel_ms": round(r.stats()["kernel_ms"], 1)})

@@ -734,6 +734,16 @@ SRT_HD f3 sky_color(float dir_y)
 // CustomVectorMath.AngleBetween / 180, squared (MiscFunctions.cs:53-60, RaytracingOperations.cs:137-140)
 SRT_HD float fresnel_term(f3 dir, f3 reflected)
 {
+#if defined(SRT_FAST_SHADING) && defined(__HIP_DEVICE_COMPILE__)
+    // experiments only (not the arithmetic contract): what the shading would cost with single-precision atan2 and fused arithmetic
+    {
+        const float dtf = __builtin_fmaf(dir.z, reflected.z, __builtin_fmaf(dir.y, reflected.y, dir.x * reflected.x));
+        const f3 cf = cross3(dir, reflected);
+        const float lenf = __builtin_amdgcn_sqrtf(__builtin_fmaf(cf.z, cf.z, __builtin_fmaf(cf.y, cf.y, cf.x * cf.x)));
+        const float ff = (3.14159274f - atan2f(lenf, dtf)) * (57.2957802f / 180.0f);
+        return ff * ff;
+    }
+#endif
     float dt = dot3(dir, reflected);
     f3 c = cross3(dir, reflected);
     float len = sqrt_rn((c.x * c.x) + (c.y * c.y) + (c.z * c.z));
@@ -765,8 +775,48 @@ SRT_HD f3 shadow_direction(const Light& L, f3 P, uint32_t word, const float* uni
 // shadow ray came back.  `former` is formerLightLevel; shadow_hit/t_s/P_s/metal_s describe
 // what the shadow ray's closest-hit query left in `record` (the occluder), metal_s being the
 // primary material's metalness when the shadow ray hit nothing.
+#if defined(SRT_FAST_SHADING) && defined(__HIP_DEVICE_COMPILE__)
+// experiments only (not the arithmetic contract): the same formulas with contraction allowed, v_rcp_f32 / v_rsq_f32 / v_sqrt_f32
+// instead of the correctly rounded operations and the fifth power in single precision.  The occlusion test keeps its exact form.
+SRT_HD f3 fast_normalize3(f3 a) { const float f = __builtin_amdgcn_rsqf(__builtin_fmaf(a.z, a.z, __builtin_fmaf(a.y, a.y, a.x * a.x))); return mk3(a.x * f, a.y * f, a.z * f); }
+SRT_HD f3 point_light_fast(const Light& L, f3 P, f3 N, f3 dir, const Material& m, f3 former, bool shadow_hit, float t_s, f3 P_s, float metal_s)
+{
+#pragma clang fp contract(fast)
+    const float roughness = 1.0f - m.smoothness, r2 = roughness * roughness;
+    const float att = clampf(__builtin_amdgcn_rcpf(distsq3(P, L.position)), 0.0f, 1.0f);
+    const f3 to_light = fast_normalize3(sub3(L.position, P)), view = fast_normalize3(neg3(dir)), half = fast_normalize3(add3(to_light, view));
+    const float NdotL = clampf(dot3(N, to_light), 0.0f, 1.0f), NdotV = clampf(dot3(N, view), 0.0f, 1.0f);
+    const float LdotH = clampf(dot3(to_light, half), 0.0f, 1.0f), NdotH = clampf(dot3(N, half), 0.0f, 1.0f);
+    const float NdotL2 = NdotL * NdotL, NdotV2 = NdotV * NdotV;
+    const float smithL = 2.0f * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_sqrtf(1.0f + r2 * (1.0f - NdotL2) * __builtin_amdgcn_rcpf(NdotL2)));
+    const float smithV = 2.0f * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_sqrtf(1.0f + r2 * (1.0f - NdotV2) * __builtin_amdgcn_rcpf(NdotV2)));
+    const float geo = smithL * smithV;
+    const float pi = 3.14159274f;
+    const float denom = NdotH * NdotH * (r2 - 1.0f) + 1.0f;
+    const float D = r2 * __builtin_amdgcn_rcpf(pi * denom * denom);
+    const float x = 1.0f - LdotH, x2 = x * x;
+    const float F = 0.5f + 0.5f * (x2 * x2 * x);
+    const float k = r2 * 0.5f;
+    const float vis = __builtin_amdgcn_rcpf(NdotL * (1.0f - k) + k) * __builtin_amdgcn_rcpf(NdotV * (1.0f - k) + k);
+    float ggx = NdotL * D * F * vis * (L.brightness * 0.5f);
+    const f3 light_albedo = add3(m.albedo, L.color);
+    f3 level = add3(former, scale3(light_albedo, (1.0f - m.metalness) * (NdotL * NdotV) * geo * L.brightness * att));
+    if (shadow_hit) {
+#pragma clang fp contract(off)
+        f3 d2 = normalize3(normalize3(sub3(L.position, P)));
+        f3 along = sub3(ray_at(P_s, d2, t_s), P_s);
+        if (lensq3(along) < lensq3(sub3(L.position, P_s))) { level = former; ggx = 0.0f; }
+    }
+    const f3 one = mk3(1.0f + L.color.x, 1.0f + L.color.y, 1.0f + L.color.z);
+    const f3 lerp = mk3(one.x + (light_albedo.x - one.x) * metal_s, one.y + (light_albedo.y - one.y) * metal_s, one.z + (light_albedo.z - one.z) * metal_s);
+    return add3(level, scale3(lerp, (1.0f / pi) * ggx * att));
+}
+#endif
 SRT_HD f3 point_light(const Light& L, f3 P, f3 N, f3 dir, const Material& m, f3 former, bool shadow_hit, float t_s, f3 P_s, float metal_s)
 {
+#if defined(SRT_FAST_SHADING) && defined(__HIP_DEVICE_COMPILE__)
+    return point_light_fast(L, P, N, dir, m, former, shadow_hit, t_s, P_s, metal_s);
+#endif
     float roughness = 1.0f - m.smoothness;
     float r2 = roughness * roughness;
     float att = clampf(1.0f / distsq3(P, L.position), 0.0f, 1.0f);

@@ -26,6 +26,7 @@
  */
 #include "srt_oracle.h"
 
+#include <atomic>
 #include <chrono>
 #include <cmath>
 #include <cstdint>
@@ -675,6 +676,11 @@ struct PointLight : Light {
     }
 };
 
+// Negative controls of the tests that compare renders with the reference's own picture: what the picture would look like
+// if the restatement had read one line differently.  Never set outside those tests.
+//   bit 0: LightList sums the lights' contributions plainly (f <- f + c_i) instead of the reference's f <- 2 f + c_i
+std::atomic<int> g_misreading{0};
+
 struct LightList : Light {
     std::vector<std::unique_ptr<PointLight>> lightArray;
     // RaytracingClasses.cs:205-218: re-intersects the ray once per light; `+=` on a value that
@@ -688,7 +694,8 @@ struct LightList : Light {
             const bool again = world->hit(ray, 0.01f, std::numeric_limits<float>::infinity(), record);
             t_repeat--;
             if (again) {
-                formerLightLevel = formerLightLevel + lightArray[i]->calculateLight(formerLightLevel, ray, world, record, key, (uint32_t)i, blinnPhong);
+                const Vec level = lightArray[i]->calculateLight(formerLightLevel, ray, world, record, key, (uint32_t)i, blinnPhong);
+                formerLightLevel = (g_misreading.load(std::memory_order_relaxed) & 1) ? level : formerLightLevel + level;
             }
         }
         return formerLightLevel;
@@ -1039,6 +1046,7 @@ void Despeckle(uint32_t* array, int width, int height, float weight, float thres
 extern "C" {
 
 const char* orc_last_error(void) { return g_error.c_str(); }
+void orc_set_misreading(int bits) { g_misreading.store(bits); }
 
 void orc_blur_array(uint32_t* array, int32_t width, int32_t height, float weight) { BlurArray(array, width, height, weight); }
 void orc_contrast_blur_array(uint32_t* array, int32_t width, int32_t height, float weight, float contrast) { ContrastBlurArray(array, width, height, weight, contrast); }

@@ -95,6 +95,9 @@ int orc_render(const orc_scene*, const orc_camera*, const orc_params*, uint32_t*
  * each divided by p->samples as the reference does, mixed pairwise into `out` in 8-bit colour. */
 int orc_render_mix_buffers(const orc_scene* s, const orc_camera* cam, const orc_params* p, int32_t n_buffers, uint32_t* out, orc_stats* stats);
 const char* orc_last_error(void);
+/* Tests only: renders made while bit 0 is set sum the lights plainly (f <- f + c) instead of the reference's
+ * f <- 2 f + c (RaytracingClasses.cs:213) -- a negative control for the comparison with the reference's own picture. */
+void orc_set_misreading(int bits);
 
 /* Constructors of the host-side classes, for known-answer tests. */
 void orc_camera_ctor(const float origin[3], const float look_at[3], float fov_deg, float ratio, orc_camera* out);

@@ -227,8 +227,10 @@ int  srt_commit_scene(srt_ctx* ctx, int world_kind);
  * A context with several devices splits the frame itself (SRT_LAYOUT_FRAME with world_size <= 1; tile_w / tile_h
  * choose the tile, 0 = 32): each device traces its tiles, the tiles are gathered on the first device, a kernel puts
  * them into the row-major frame and one copy brings it to rgba_out.  The picture does not depend on the number of
- * devices.  srt_render, srt_render_counted, srt_render_async / srt_poll / srt_wait and srt_get_stats work that way;
- * every other entry point of such a context runs on its first device alone. */
+ * devices.  srt_render, srt_render_counted, srt_render_async / srt_poll / srt_wait, srt_render_progressive (tiles gathered
+ * and assembled after every pass), srt_render_mix_buffers (every device renders whole one-sample buffers, the first
+ * device mixes them in buffer order) and srt_get_stats work on all devices; srt_render_device,
+ * srt_render_device_static, srt_assemble_tiles and the post-process filters run on the first device alone. */
 int  srt_render(srt_ctx* ctx, const srt_render_params* p, uint32_t* rgba_out);
 /* Same, writing to device memory on the caller's HIP stream (hipStream_t passed as void*; NULL is HIP's
  * default stream) without synchronising: the host side of a multi-GPU job keeps the tiles on the device
@@ -271,7 +273,8 @@ int  srt_read_preview(srt_ctx* ctx, uint32_t* rgba_out);
  * the colour still divided by p->samples (:352), then gamma and packing -- and Game1.Update mixes the buffers into
  * buffer1Data one after the other in 8-bit colour: new Color(buffer1Data.ToVector3() / 2 + buffer.ToVector3() / 2)
  * (:209-220), starting from default (zero) Colors.  Buffer b is traced with sample index b of the counter RNG (thread
- * b's System.Random).  Blocking; SRT_LAYOUT_FRAME, world_size 1 and SRT_MODE_COLOR only. */
+ * b's System.Random).  Blocking; SRT_LAYOUT_FRAME, world_size 1 and SRT_MODE_COLOR only.  A context with several devices
+ * renders buffer b on device b % n_devices and mixes on the first device, in buffer order: the same picture. */
 int  srt_render_mix_buffers(srt_ctx* ctx, const srt_render_params* p, int32_t n_buffers, uint32_t* rgba_out);
 
 /* The post-process filters of the finished picture: Sorting.BlurArray (MiscFunctions.cs:124-191), Sorting.ContrastBlurArray

@@ -279,8 +279,13 @@ struct Workspace {
 
 // min_passes > 1 (progressive renders): at least that many passes, each followed by a preview in d_out, a copy of it
 // to pinned memory and an event.
+// One pass of a render whose passes the caller schedules itself (contexts with several devices: the mix-buffer technique and
+// progressive renders, where something happens between the passes of the devices): samples [first_sample, first_sample + count),
+// resolved into d_out -- added to the running sums unless it is both the first and the last pass.
+struct PassSpec { int first_sample = 0, count = 1; bool first = true, last = true; float preview = 0.0f; };
+
 int launch(srt_ctx* c, DeviceState& d, const srt_render_params* p, uint32_t* d_out, size_t capacity, hipStream_t stream, bool counted,
-           int min_passes = 1, int mix_buffers = 0, const Workspace* fixed_ws = nullptr)
+           int min_passes = 1, int mix_buffers = 0, const Workspace* fixed_ws = nullptr, const PassSpec* one_pass = nullptr)
 {
     if (!c->committed) return fail(c, SRT_E_STATE, "srt_commit_scene has not been called");
     if (!c->has_camera) return fail(c, SRT_E_STATE, "srt_set_camera has not been called");
@@ -311,6 +316,10 @@ int launch(srt_ctx* c, DeviceState& d, const srt_render_params* p, uint32_t* d_o
         per_pass = 1;
     }
     if (per_pass > (uint64_t)ra.samples) per_pass = (uint64_t)ra.samples;
+    if (one_pass) {
+        if ((uint64_t)one_pass->count > per_pass) return fail(c, SRT_E_LIMIT, "a pass of this size does not fit the sample buffer");
+        per_pass = (uint64_t)one_pass->count;
+    }
     if (mix_buffers > 0) {
         if (ra.layout != 0 || ra.world_size != 1) return fail(c, SRT_E_INVALID, "the mix-buffer technique renders whole frames (SRT_LAYOUT_FRAME, world_size 1)");
         if ((uint32_t)ra.mode != MODE_COLOR) return fail(c, SRT_E_INVALID, "the mix-buffer technique calls GetRayColor (SRT_MODE_COLOR)");
@@ -330,7 +339,7 @@ int launch(srt_ctx* c, DeviceState& d, const srt_render_params* p, uint32_t* d_o
         }
     }
     const size_t need_samples = (size_t)(per_pass * per_sample);
-    const bool multi_pass = per_pass < (uint64_t)ra.samples;
+    const bool multi_pass = one_pass ? !(one_pass->first && one_pass->last) : per_pass < (uint64_t)ra.samples;
     Workspace ws;
     if (fixed_ws) {
         ws = *fixed_ws;
@@ -369,7 +378,7 @@ int launch(srt_ctx* c, DeviceState& d, const srt_render_params* p, uint32_t* d_o
         if (d.launched && d.last_stream != stream) SRT_HIP(c, hipStreamWaitEvent(stream, d.ev_end, 0));
         d.last_stream = stream;
         d.launched = true;
-        SRT_HIP(c, hipEventRecord(d.ev_begin, stream));
+        if (!one_pass || one_pass->first) SRT_HIP(c, hipEventRecord(d.ev_begin, stream));
     }
     const SceneView view = scene_view(c, d);
     const bool exact = c->world_kind == SRT_WORLD_BVHNODE;
@@ -389,6 +398,20 @@ int launch(srt_ctx* c, DeviceState& d, const srt_render_params* p, uint32_t* d_o
         }
         SRT_HIP(c, hipEventRecord(d.ev_end, stream));
         d.stats_pending = true;
+        return SRT_OK;
+    }
+    if (one_pass) {
+        ra.sample_first = (uint32_t)one_pass->first_sample;
+        ra.sample_count = (uint32_t)one_pass->count;
+        ra.n_items = ra.n_work * ra.sample_count;
+        hipError_t e = launch_trace(view, ra, exact, counted, ws.samples, d.d_stats, ws.counter, d.d_timeline, d.d_frame_slab, d.slab_bytes, stream, d.walk_tune);
+        if (e != hipSuccess) return hip_fail(c, e, "trace kernel launch");
+        e = launch_resolve(ra, ws.samples, ws.running, d_out, one_pass->first, one_pass->last, one_pass->preview, stream);
+        if (e != hipSuccess) return hip_fail(c, e, "resolve kernel launch");
+        if (!recorded) {
+            SRT_HIP(c, hipEventRecord(d.ev_end, stream));
+            d.stats_pending = true;
+        }
         return SRT_OK;
     }
     int pass = 0;
@@ -515,6 +538,106 @@ int launch_multi(srt_ctx* c, const srt_render_params* p, bool counted, MultiPlan
     return render_multi(backend, plan);
 }
 
+// The mix-buffer technique on the devices of a context: the reference gives every thread a frame of its own to render
+// (Game1.cs:174-175, 382-394), so every device renders whole one-sample frames -- buffer b on device b % n -- and hands
+// them to the first device, which mixes them into the picture in buffer order, as Game1.Update does (:209-220; the mix
+// rounds to 8 bits after every buffer, so the order is part of the result).  The picture ends up in c->d_frame.
+int launch_mix_multi(srt_ctx* c, const srt_render_params* p, int n_buffers)
+{
+    const int n = (int)c->dev.size();
+    if (p->layout != SRT_LAYOUT_FRAME || p->world_size > 1 || p->rank != 0)
+        return fail(c, SRT_E_INVALID, "the mix-buffer technique renders whole frames (SRT_LAYOUT_FRAME, world_size 1)");
+    if (p->mode != SRT_MODE_COLOR) return fail(c, SRT_E_INVALID, "the mix-buffer technique calls GetRayColor (SRT_MODE_COLOR)");
+    const int64_t px = output_pixels(p);
+    if (px < 0) { RenderArgs ra; return make_render_args(p, c->cam, ra, c->error); }
+    MultiPlan plan;
+    plan.n = n;
+    plan.stride = px;
+    plan.frame_pixels = px;
+    HipDevices backend{c, false};
+    for (int k = 0; k < n; k++) plan.pixels[k] = px;
+    int rc = backend.prepare(plan);
+    DeviceState& root = c->dev[0];
+    for (int b0 = 0; b0 < n_buffers && rc == SRT_OK; b0 += n) {
+        for (int k = 0; k < n && rc == SRT_OK; k++) {
+            plan.pixels[k] = b0 + k < n_buffers ? px : 0;
+            if (plan.pixels[k] == 0) continue;
+            DeviceState& d = c->dev[k];
+            // the first device keeps the buffers of a round side by side; nobody writes there before it has mixed the last round
+            if (k > 0 && b0 > 0) { SRT_HIP(c, hipSetDevice(d.device)); SRT_HIP(c, hipStreamWaitEvent(d.stream, c->ev_assembled, 0)); }
+            // renderBlockFull (Game1.cs:320-374) for one buffer: sample index b of the counter RNG stands for thread b's
+            // System.Random; the colour is divided by `samples`, then gamma and packing
+            PassSpec buffer;
+            buffer.first_sample = b0 + k;
+            rc = launch(c, d, p, k == 0 ? c->d_gathered : d.d_out, (size_t)px, d.stream, false, 1, 0, nullptr, &buffer);
+        }
+        if (rc == SRT_OK) rc = backend.gather(plan);
+        if (rc != SRT_OK) break;
+        SRT_HIP(c, hipSetDevice(root.device));
+        for (int k = 0; k < n; k++) {
+            if (plan.pixels[k] == 0) continue;
+            hipError_t e = launch_mix(c->d_frame, c->d_gathered + (size_t)k * (size_t)px, (uint32_t)px, b0 + k == 0, root.stream);
+            if (e != hipSuccess) return hip_fail(c, e, "mix kernel launch");
+        }
+        SRT_HIP(c, hipEventRecord(c->ev_assembled, root.stream));
+        c->multi_pending = true;
+    }
+    return rc;
+}
+
+// A progressive render on the devices of a context: every pass is traced by all devices (each its own tiles, with running
+// sums of its own), and after every pass the tiles are gathered and assembled on the first device and the preview goes to
+// pinned host memory, with an event behind it.  The passes are sized for the first device, which owns the most tiles.
+int launch_progressive_multi(srt_ctx* c, const srt_render_params* p, int min_passes)
+{
+    MultiPlan plan;
+    int rc = plan_multi(p, (int)c->dev.size(), plan, c->error);
+    if (rc != SRT_OK) return rc;
+    HipDevices backend{c, false};
+    if ((rc = backend.prepare(plan)) != SRT_OK) return rc;
+    RenderArgs ra0;
+    if ((rc = make_render_args(&plan.part[0], c->cam, ra0, c->error)) != SRT_OK) return rc;
+    const uint64_t samples = (uint64_t)p->samples, per_sample = (uint64_t)(ra0.n_work ? ra0.n_work : 1u) * 12u;
+    const uint64_t by_items = (((uint64_t)1 << 31) - 1) / (ra0.n_work ? ra0.n_work : 1u);
+    uint64_t per_pass = c->sample_budget / per_sample;
+    if (per_pass > by_items) per_pass = by_items;
+    if (per_pass < 1) per_pass = 1;
+    const uint64_t share = (samples + (uint64_t)min_passes - 1) / (uint64_t)min_passes;
+    if (per_pass > share) per_pass = share;
+    const uint64_t floor_pp = (samples + srt_ctx::MAX_PASSES - 1) / srt_ctx::MAX_PASSES;   // never more passes than events
+    if (per_pass < floor_pp) {
+        if (floor_pp * per_sample > c->sample_budget || floor_pp > by_items) return fail(c, SRT_E_LIMIT, "a progressive render of this size needs more than 64 passes");
+        per_pass = floor_pp;
+    }
+    DeviceState& root = c->dev[0];
+    const size_t frame_bytes = (size_t)plan.frame_pixels * sizeof(uint32_t);
+    int pass = 0;
+    for (uint64_t s0 = 0; s0 < samples; s0 += per_pass, pass++) {
+        PassSpec spec;
+        spec.first_sample = (int)s0;
+        spec.count = (int)(samples - s0 < per_pass ? samples - s0 : per_pass);
+        spec.first = s0 == 0;
+        spec.last = s0 + (uint64_t)spec.count >= samples;
+        spec.preview = (float)samples / (float)(s0 + (uint64_t)spec.count);
+        for (int k = 0; k < plan.n; k++) {
+            DeviceState& d = c->dev[k];
+            if (plan.pixels[k] == 0) continue;
+            // the first device keeps every device's tiles side by side: nobody writes there before it has assembled the last pass
+            if (k > 0 && pass > 0) { SRT_HIP(c, hipSetDevice(d.device)); SRT_HIP(c, hipStreamWaitEvent(d.stream, c->ev_assembled, 0)); }
+            rc = launch(c, d, &plan.part[k], k == 0 ? c->d_gathered : d.d_out, (size_t)plan.pixels[k], d.stream, false, 1, 0, nullptr, &spec);
+            if (rc != SRT_OK) return rc;
+        }
+        if ((rc = backend.gather(plan)) != SRT_OK) return rc;
+        if ((rc = backend.assemble(plan)) != SRT_OK) return rc;
+        SRT_HIP(c, hipSetDevice(root.device));
+        SRT_HIP(c, hipMemcpyAsync(c->h_pinned, c->d_frame, frame_bytes, hipMemcpyDeviceToHost, root.stream));
+        if (!c->pass_done[pass]) SRT_HIP(c, hipEventCreateWithFlags(&c->pass_done[pass], hipEventDisableTiming));
+        SRT_HIP(c, hipEventRecord(c->pass_done[pass], root.stream));
+    }
+    c->passes_total = pass;
+    return SRT_OK;
+}
+
 int render_blocking(srt_ctx* c, const srt_render_params* p, uint32_t* rgba_out, bool counted, int mix_buffers = 0)
 {
     if (!c) return SRT_E_INVALID;
@@ -527,7 +650,10 @@ int render_blocking(srt_ctx* c, const srt_render_params* p, uint32_t* rgba_out, 
     int rc = collect_stats(c);  // a blocking render reports its own counters only
     if (rc != SRT_OK) return rc;
     const uint32_t* src;
-    if (c->dev.size() > 1 && mix_buffers == 0) {
+    if (c->dev.size() > 1 && mix_buffers > 0) {
+        if ((rc = launch_mix_multi(c, p, mix_buffers)) != SRT_OK) return rc;
+        src = c->d_frame;
+    } else if (c->dev.size() > 1) {
         MultiPlan plan;
         if ((rc = launch_multi(c, p, counted, plan)) != SRT_OK) return rc;
         src = c->d_frame;
@@ -861,7 +987,11 @@ static int start_async(srt_ctx* c, const srt_render_params* p, uint32_t* rgba_ou
     }
     int rc;
     const uint32_t* src;
-    if (c->dev.size() > 1 && passes == 1) {
+    if (c->dev.size() > 1 && passes > 1) {
+        if ((rc = launch_progressive_multi(c, p, passes)) != SRT_OK) return rc;
+        src = c->d_frame;
+        SRT_HIP(c, hipSetDevice(d.device));
+    } else if (c->dev.size() > 1) {
         MultiPlan plan;
         if ((rc = launch_multi(c, p, false, plan)) != SRT_OK) return rc;
         src = c->d_frame;

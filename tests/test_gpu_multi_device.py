@@ -130,3 +130,60 @@ def test_c_host_over_several_devices_writes_the_same_frame(tmp_path):
         subprocess.run([exe, "160", "90", "3", "4", "7", str(out), "0", devices], check=True, timeout=100)
         frames.append(out.read_bytes())
     assert frames[0] == frames[1]
+
+
+@pytest.mark.parametrize("n_devices,n_buffers", [(2, 5), (3, 3), (3, 8), (8, 4)])
+def test_mix_buffers_over_several_devices_is_the_single_device_picture(single, n_devices, n_buffers):
+    """The mix-buffer technique (Game1.cs:174-175, 209-220): every device renders whole one-sample frames, the first device
+    mixes them in buffer order -- the picture and the ray counts are those of one device."""
+    w, h = 160, 90
+    world, lights, cam = helpers.default_spec().host(w, h)
+    single.set_scene(world, lights, cam)
+    ref = single.render_mix_buffers(w, h, n_buffers, samples=2, max_depth=6, seed=4)
+    ref_st = single.stats()
+    multi = srt.Renderer(devices=[0] * n_devices)
+    multi.set_scene(world, lights, cam)
+    img = multi.render_mix_buffers(w, h, n_buffers, samples=2, max_depth=6, seed=4)
+    st = multi.stats()
+    assert np.array_equal(img, ref)
+    assert st["rays_path"] == ref_st["rays_path"] and st["rays_shadow"] == ref_st["rays_shadow"]
+    parts = [multi.device_stats(i)["rays_path"] for i in range(n_devices)]
+    assert sum(parts) == st["rays_path"] and all(p > 0 for p in parts[:min(n_devices, n_buffers)])
+    # and again through the same context (the buffers of the first render are reused)
+    assert np.array_equal(multi.render_mix_buffers(w, h, n_buffers, samples=2, max_depth=6, seed=4), ref)
+    multi.close()
+
+
+@pytest.mark.parametrize("n_devices", [2, 3])
+def test_progressive_render_over_several_devices(single, n_devices):
+    """The picture that fills in while it renders (Game1.cs:188-201), with the frame split over the devices of the context:
+    after every pass a complete preview, at the end the frame one device renders."""
+    w, h, spp = 200, 120, 12
+    world, lights, cam = helpers.default_spec().host(w, h)
+    single.set_scene(world, lights, cam)
+    want = single.render(w, h, samples=spp, max_depth=6, seed=3)
+    want_st = single.stats()
+    multi = srt.Renderer(devices=[0] * n_devices)
+    multi.set_scene(world, lights, cam)
+    p = multi.params(w, h, samples=spp, max_depth=6, seed=3)
+    out, preview = np.zeros(w * h, dtype=np.uint32), np.zeros(w * h, dtype=np.uint32)
+    multi.render_progressive(p, out, 4)
+    seen, polls = set(), 0
+    while True:
+        done, total = multi.progress()
+        assert total == 4 and 0 <= done <= 4
+        if done >= 1 and done not in seen:
+            multi.read_preview(preview)
+            seen.add(done)
+            assert (preview >> 24 == 255).all()           # a complete picture: every tile of every device has arrived
+        if multi.poll():
+            break
+        polls += 1
+        assert polls < 10_000_000
+    assert np.array_equal(out.reshape(h, w), want)
+    st = multi.stats()
+    assert st["rays_path"] == want_st["rays_path"] and st["rays_shadow"] == want_st["rays_shadow"]
+    # the context renders as usual afterwards
+    assert np.array_equal(multi.render(w, h, samples=spp, max_depth=6, seed=3), want)
+    assert multi.progress() == (0, 0)
+    multi.close()

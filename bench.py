@@ -70,7 +70,7 @@ CONFIGS = {
 # FETCH_SIZE and WRITE_SIZE are in KiB, and FETCH_SIZE is doubled, the correction for gfx950).  A normal run has no
 # profiler attached, so it reads the digest of those passes (tools/pmc_bench_digest.py writes it): per configuration the
 # bytes per frame and the L2 request rate, with the profile they come from.
-TRAFFIC_DIGEST = os.path.join(ROOT, "profiles", "r3_traffic_digest.json")
+TRAFFIC_DIGEST = os.path.join(ROOT, "bench_traffic.json")   # at the top of the tree: profiles/ does not travel to the GPU box
 
 # Algorithmic work per event: bytes fetched / FP32 operations (add, sub, mul, div, sqrt, min, max, compare = 1 each)
 # of the reference algorithm, excluding work the GPU legitimately skips.

@@ -3,7 +3,7 @@
 # Counter passes of one benchmark configuration at its stated size (each pass is a run of bench.py of its own), and a
 # kernel trace:  gpurun_out/pmcb_<label>_trace  rocprofv3 --kernel-trace --stats
 #                gpurun_out/pmcb_<label>_{1,2,3}  FETCH_SIZE + TCC_REQ, WRITE_SIZE + TCC hit / miss, SQ lane utilisation
-# tools/pmc_bench_digest.py turns them into profiles/<label>_pmc.txt and an entry of profiles/r3_traffic_digest.json.
+# tools/pmc_bench_digest.py turns them into profiles/<label>_pmc.txt and an entry of bench_traffic.json.
 L=$1; STEPS=$2; shift; shift
 export TMPDIR=/tmp
 R=${GRAFT_REPO_ROOT:-$(pwd)}

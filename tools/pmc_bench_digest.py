@@ -3,7 +3,7 @@
     python tools/pmc_bench_digest.py <label> <config> <steps>
 
 writes profiles/<label>_pmc.txt (per-kernel counter averages per launch, the kernel trace's statistics) and adds the
-configuration's entry to profiles/r3_traffic_digest.json: counter sums PER FRAME (a frame of the big configurations is
+configuration's entry to bench_traffic.json: counter sums PER FRAME (a frame of the big configurations is
 several launches of the trace kernel: the counters are summed over the launches of the run and divided by its frames).
 """
 import collections
@@ -53,7 +53,7 @@ def main():
     with open(os.path.join(ROOT, "profiles", "%s_pmc.txt" % label), "w") as f:
         f.write("python bench.py --config %s --steps %d --warmup 1 --no-cpu-baseline under rocprofv3 (three --pmc passes, one --kernel-trace --stats pass)\n" % (config, steps))
         f.write("\n".join(lines) + "\n\n" + stats)
-    path = os.path.join(ROOT, "profiles", "r3_traffic_digest.json")
+    path = os.path.join(ROOT, "bench_traffic.json")
     digest = json.load(open(path)) if os.path.exists(path) else {}
     digest[config] = entry
     json.dump(digest, open(path, "w"), indent=1, sort_keys=True)

@@ -178,6 +178,13 @@ typedef struct {
                     the transfers and the wait for the slowest device;
        assemble_ms  the kernel that puts the gathered tiles into the row-major frame. */
     double   gather_ms, assemble_ms;
+    /* Scenes whose tree is walked with a stack, once their renders have shown more than a few rays per sample: the ray
+       trees are traced level by level through a pool of node records in device memory (one kernel per part of
+       GetRayColor and level) instead of one tree per lane.  Work items (samples) traced that way in the last render, the
+       node records they took (reservation holes included), and the chunks of items whose trees outgrew the pool and
+       were traced by the one-kernel tracer after all (same colours, same counts).  The items include the padding pixels
+       of edge tiles. */
+    uint64_t wavefront_items, wavefront_nodes, wavefront_given_up;
 } srt_stats;
 
 typedef struct srt_ctx srt_ctx;

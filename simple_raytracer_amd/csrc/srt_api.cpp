@@ -99,6 +99,15 @@ struct DeviceState {
     // Traversal quantum of the mesh kernel for the committed scene: measured by the first launches after a commit
     // (WALK_TUNE_CALIBRATE), then fixed to what they found.
     int walk_tune = WALK_TUNE_CALIBRATE;
+    // Node pool of the level-by-level tracer: allocated by the first render of a scene that tracer serves
+    // (SRT_WAVEFRONT_POOL_MB, at most half of the free memory), kept until the context goes.
+    WavefrontPool wavefront;
+    bool wavefront_tried = false;
+    // GetRayColor calls per work item in the renders of the committed scene so far (0: none collected yet).  The
+    // level-by-level tracer pays per item for streaming the first level through memory and gains per node of the deeper
+    // levels, so it takes over once this is above SRT_WAVEFRONT_MIN_RAYS (default 5).
+    double rays_per_item = 0.0;
+    uint64_t items_since_collect = 0;
 };
 
 }  // namespace
@@ -205,6 +214,7 @@ void zero_counts(srt_stats& s)
     s.trace_sections = s.trace_lanes = s.light_sections = s.light_lanes = 0;
     for (int i = 0; i < 16; i++) s.section_cycles[i] = s.section_lane_cycles[i] = 0;
     s.shadow_unasked = 0;
+    s.wavefront_items = s.wavefront_nodes = s.wavefront_given_up = 0;
     s.kernel_ms = 0.0;
 }
 
@@ -239,6 +249,12 @@ int collect_stats(srt_ctx* c)
         p.shadow_unasked = s[48];
         if (d.walk_tune == WALK_TUNE_CALIBRATE && s[13] >= kWalkTuneEnoughTicks && s[15] >= kWalkTuneEnoughTicks)
             d.walk_tune = walk_tune_prefers_short((double)s[12], (double)s[13], (double)s[14], (double)s[15]) ? WALK_TUNE_SHORT : WALK_TUNE_LONG;
+        // nodes per work item of the level-by-level tracer's chunks: the next launches size their chunks by it
+        if (s[kStatsWavefrontItems] != 0ull) d.wavefront.nodes_per_item = (double)s[kStatsWavefrontNodes] / (double)s[kStatsWavefrontItems];
+        if (s[kStatsWavefrontGivenUp] != 0ull) d.wavefront.nodes_per_item = 2.0 * (d.wavefront.nodes_per_item > 0.0 ? d.wavefront.nodes_per_item : 24.0);
+        p.wavefront_items = s[kStatsWavefrontItems]; p.wavefront_nodes = s[kStatsWavefrontNodes]; p.wavefront_given_up = s[kStatsWavefrontGivenUp];
+        if (d.items_since_collect != 0) d.rays_per_item = (double)s[0] / (double)d.items_since_collect;
+        d.items_since_collect = 0;
         p.kernel_ms = ms;
         d.stats_pending = false;
         alarm = alarm || s[11] != 0ull;
@@ -261,6 +277,7 @@ int collect_stats(srt_ctx* c)
         t.trace_sections += p.trace_sections; t.trace_lanes += p.trace_lanes; t.light_sections += p.light_sections; t.light_lanes += p.light_lanes;
         for (int i = 0; i < 16; i++) { t.section_cycles[i] += p.section_cycles[i]; t.section_lane_cycles[i] += p.section_lane_cycles[i]; }
         t.shadow_unasked += p.shadow_unasked;
+        t.wavefront_items += p.wavefront_items; t.wavefront_nodes += p.wavefront_nodes; t.wavefront_given_up += p.wavefront_given_up;
         if (p.kernel_ms > t.kernel_ms) t.kernel_ms = p.kernel_ms;
     }
     c->stats.walk_tune = (uint32_t)c->dev[0].walk_tune;
@@ -382,6 +399,22 @@ int launch(srt_ctx* c, DeviceState& d, const srt_render_params* p, uint32_t* d_o
     }
     const SceneView view = scene_view(c, d);
     const bool exact = c->world_kind == SRT_WORLD_BVHNODE;
+    const WavefrontPool* wavefront = nullptr;
+    const char* min_rays_knob = std::getenv("SRT_WAVEFRONT_MIN_RAYS");   // read per launch: tests switch tracers inside one process
+    const double min_rays = min_rays_knob ? std::atof(min_rays_knob) : 5.0;
+    if (std::getenv("SRT_DEBUG_LAUNCH")) std::fprintf(stderr, "srt: rays per item %.2f (level-by-level tracer from %.2f), serves %d\n", d.rays_per_item, min_rays, (int)wavefront_serves(view, ra, exact));
+    if (!fixed_ws && d.rays_per_item >= min_rays && wavefront_serves(view, ra, exact)) {
+        if (!d.wavefront_tried && !recorded) {
+            d.wavefront_tried = true;
+            size_t free_b = 0, total_b = 0;
+            size_t want = (size_t)16384 << 20;
+            if (const char* mb = std::getenv("SRT_WAVEFRONT_POOL_MB")) want = (size_t)std::atoll(mb) << 20;
+            if (hipMemGetInfo(&free_b, &total_b) == hipSuccess && want > free_b / 2) want = free_b / 2;
+            if (wavefront_capacity(want) != 0u && hipMalloc(&d.wavefront.mem, want) == hipSuccess) d.wavefront.bytes = want;
+            else { d.wavefront.mem = nullptr; (void)hipGetLastError(); }
+        }
+        if (d.wavefront.mem) wavefront = &d.wavefront;
+    }
     if (mix_buffers > 0) {
         // renderBlockFull (Game1.cs:320-374) once per buffer: one sample -- sample index b of the counter RNG stands for
         // thread b's System.Random -- divided by `samples`, gamma, packing; then the pairwise mix of Game1.cs:209-220
@@ -389,7 +422,8 @@ int launch(srt_ctx* c, DeviceState& d, const srt_render_params* p, uint32_t* d_o
             ra.sample_first = (uint32_t)b;
             ra.sample_count = 1u;
             ra.n_items = ra.n_work;
-            hipError_t e = launch_trace(view, ra, exact, counted, ws.samples, d.d_stats, ws.counter, d.d_timeline, d.d_frame_slab, d.slab_bytes, stream, d.walk_tune);
+            hipError_t e = launch_trace(view, ra, exact, counted, ws.samples, d.d_stats, ws.counter, d.d_timeline, d.d_frame_slab, d.slab_bytes, stream, d.walk_tune, wavefront);
+            d.items_since_collect += ra.n_items;
             if (e != hipSuccess) return hip_fail(c, e, "trace kernel launch");
             e = launch_resolve(ra, ws.samples, ws.running, c->d_mix, true, true, 0.0f, stream);
             if (e != hipSuccess) return hip_fail(c, e, "resolve kernel launch");
@@ -404,7 +438,8 @@ int launch(srt_ctx* c, DeviceState& d, const srt_render_params* p, uint32_t* d_o
         ra.sample_first = (uint32_t)one_pass->first_sample;
         ra.sample_count = (uint32_t)one_pass->count;
         ra.n_items = ra.n_work * ra.sample_count;
-        hipError_t e = launch_trace(view, ra, exact, counted, ws.samples, d.d_stats, ws.counter, d.d_timeline, d.d_frame_slab, d.slab_bytes, stream, d.walk_tune);
+        hipError_t e = launch_trace(view, ra, exact, counted, ws.samples, d.d_stats, ws.counter, d.d_timeline, d.d_frame_slab, d.slab_bytes, stream, d.walk_tune, wavefront);
+            d.items_since_collect += ra.n_items;
         if (e != hipSuccess) return hip_fail(c, e, "trace kernel launch");
         e = launch_resolve(ra, ws.samples, ws.running, d_out, one_pass->first, one_pass->last, one_pass->preview, stream);
         if (e != hipSuccess) return hip_fail(c, e, "resolve kernel launch");
@@ -419,7 +454,8 @@ int launch(srt_ctx* c, DeviceState& d, const srt_render_params* p, uint32_t* d_o
         ra.sample_first = s0;
         ra.sample_count = (uint32_t)ra.samples - s0 < (uint32_t)per_pass ? (uint32_t)ra.samples - s0 : (uint32_t)per_pass;
         ra.n_items = ra.n_work * ra.sample_count;
-        hipError_t e = launch_trace(view, ra, exact, counted, ws.samples, d.d_stats, ws.counter, d.d_timeline, d.d_frame_slab, d.slab_bytes, stream, d.walk_tune);
+        hipError_t e = launch_trace(view, ra, exact, counted, ws.samples, d.d_stats, ws.counter, d.d_timeline, d.d_frame_slab, d.slab_bytes, stream, d.walk_tune, wavefront);
+            d.items_since_collect += ra.n_items;
         if (e != hipSuccess) return hip_fail(c, e, "trace kernel launch");
         const uint32_t done = s0 + ra.sample_count;
         const float preview = progressive ? (float)ra.samples / (float)done : 0.0f;
@@ -702,6 +738,7 @@ void destroy_device(DeviceState& d)
     if (d.d_stats) hipFree(d.d_stats);
     if (d.d_counter) hipFree(d.d_counter);
     if (d.d_timeline) hipFree(d.d_timeline);
+    if (d.wavefront.mem) hipFree(d.wavefront.mem);
     if (d.d_frame_slab) hipFree(d.d_frame_slab);
     if (d.d_samples) hipFree(d.d_samples);
     if (d.d_running) hipFree(d.d_running);
@@ -905,6 +942,9 @@ int srt_commit_scene(srt_ctx* c, int world_kind)
         SRT_HIP(c, hipStreamSynchronize(d.stream));
         free_scene_buffers(d);
         d.walk_tune = WALK_TUNE_CALIBRATE;
+        d.wavefront.nodes_per_item = 0.0;
+        d.rays_per_item = 0.0;
+        d.items_since_collect = 0;
         if ((rc = upload(c, c->flat.nodes, &d.d_nodes)) != SRT_OK) return rc;
         if ((rc = upload(c, c->flat.prims, &d.d_prims)) != SRT_OK) return rc;
         if ((rc = upload(c, c->flat.normals, &d.d_normals)) != SRT_OK) return rc;

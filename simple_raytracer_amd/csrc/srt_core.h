@@ -242,7 +242,10 @@ SRT_HD f3 random_hemisphere_vector(const RngKey& k, f3 normal, const float* unit
 enum : uint32_t { PRIM_TRI = 0u, PRIM_SPHERE = 1u, PRIM_RECT = 2u };
 enum : uint32_t { INFO_FLIP = 4u, INFO_BLEND = 8u };
 enum : uint32_t { DESC_LEAF = 0x80000000u, NO_PRIM = 0xFFFFFFFFu };
-enum { STACK_DEPTH = 36, MAX_LEAF_PRIMS = 16, FRAME_SLOTS = 16, TINY_TREE_NODES = 64 };
+#ifndef SRT_STACK_DEPTH
+#define SRT_STACK_DEPTH 36
+#endif
+enum { STACK_DEPTH = SRT_STACK_DEPTH, MAX_LEAF_PRIMS = 16, FRAME_SLOTS = 16, TINY_TREE_NODES = 64 };
 
 // Primitive record, 3 words (48 bytes):
 //   tri:    (A.x A.y A.z AB.x) (AB.y AB.z AC.x AC.y) (AC.z  info order normal_index)
@@ -598,12 +601,11 @@ SRT_HD void trav_begin(const SceneView& sc, f3 o, float t_min, Trav& tr, uint32_
 }
 
 // PAD: widen every box by tr.pad on all sides (queries that start far outside the scene, see trav_begin).
+// trav_run_with: the caller keeps a = |d|^2 and inv = 1 / d across calls (a kernel that resumes a traversal many times).
 template <bool EXACT, bool COUNT, int STRIDE, bool PAD = false>
-SRT_HD void trav_run(const SceneView& sc, f3 o, float t_min, Trav& tr, uint32_t* stack_mem, Counters& cnt, int rounds, int steps)
+SRT_HD void trav_run_with(const SceneView& sc, f3 o, float a, f3 inv, float t_min, Trav& tr, uint32_t* stack_mem, Counters& cnt, int rounds, int steps)
 {
     const f3 d = tr.d;
-    const float a = lensq3(d);
-    const f3 inv = mk3(1.0f / d.x, 1.0f / d.y, 1.0f / d.z);  // CustomRay.dirFrac (RaytracingClasses.cs:16-18)
     LaneStack<STRIDE> st;
     st.base = stack_mem; st.sp = tr.sp;
     Hit best = tr.best;
@@ -663,6 +665,13 @@ SRT_HD void trav_run(const SceneView& sc, f3 o, float t_min, Trav& tr, uint32_t*
         }
     }
     tr.cur = cur; tr.sp = st.sp; tr.best = best;
+}
+template <bool EXACT, bool COUNT, int STRIDE, bool PAD = false>
+SRT_HD void trav_run(const SceneView& sc, f3 o, float t_min, Trav& tr, uint32_t* stack_mem, Counters& cnt, int rounds, int steps)
+{
+    const f3 d = tr.d;
+    const f3 inv = mk3(1.0f / d.x, 1.0f / d.y, 1.0f / d.z);  // CustomRay.dirFrac (RaytracingClasses.cs:16-18)
+    trav_run_with<EXACT, COUNT, STRIDE, PAD>(sc, o, lensq3(d), inv, t_min, tr, stack_mem, cnt, rounds, steps);
 }
 
 // ------------------------------------------------------------------------------------------

@@ -537,8 +537,10 @@ template <bool EXACT, bool COUNT>
 __global__ void __launch_bounds__(kBlock, SRT_WAVES_PER_SIMD_MESH) mesh_trace_kernel(SceneView sc, RenderArgs ra, f3* __restrict__ samples,
                                                             unsigned long long* __restrict__ stats, uint32_t* __restrict__ work_counter,
                                                             float4* __restrict__ timeline /* -DSRT_TIMELINE builds only */, q4* __restrict__ frame_slab, WalkTune tune, uint32_t chunk, uint32_t guide, int share,
-                                                            int steady_depth)
+                                                            int steady_depth, const uint32_t* __restrict__ run_if)
 {
+    // a launch that stands by for the level-by-level tracer: it runs only if that one gave its chunk of items up
+    if (run_if != nullptr && *run_if == 0u) return;
     __shared__ uint32_t lds_stack[kWaves * STACK_DEPTH * 64];
     __shared__ uint32_t lds_pair[kWaves * 64];   // handing over subtrees: giver lane by rank
     __shared__ float unit[UNIT_TABLE];   // (d - 100) / 100 for the RNG's base-200 digits
@@ -871,7 +873,8 @@ static uint32_t resident_blocks(K kernel)
 }
 
 hipError_t launch_trace(const SceneView& sc, const RenderArgs& ra_in, bool exact, bool counted, float* d_samples,
-                        unsigned long long* d_stats, uint32_t* d_work_counter, float* d_timeline, void* d_frame_slab, size_t slab_bytes, hipStream_t stream, int walk_tune)
+                        unsigned long long* d_stats, uint32_t* d_work_counter, float* d_timeline, void* d_frame_slab, size_t slab_bytes, hipStream_t stream, int walk_tune,
+                        const WavefrontPool* wavefront)
 {
     if (ra_in.n_items == 0u) return hipSuccess;
     if (slab_bytes < trace_frame_slab_block_bytes()) return hipErrorInvalidValue;
@@ -948,7 +951,42 @@ hipError_t launch_trace(const SceneView& sc, const RenderArgs& ra_in, bool exact
         static const uint32_t scatter_env = scatter_knob ? (uint32_t)std::atoi(std::getenv("SRT_MESH_SCATTER_SAMPLES")) : 0u;
         const uint32_t mesh_scatter = scatter_knob ? scatter_env : (tune.mode == WALK_TUNE_SHORT ? kShortScatterSamples : 0u);
         set_item_order(ra, mesh_scatter);
-#define SRT_LAUNCH_MESH(E, C) hipLaunchKernelGGL((mesh_trace_kernel<E, C>), grid, block, 0, stream, sc, ra, s, d_stats, d_work_counter, timeline, slab, tune, chunk, guide, share, steady_depth)
+        // The level-by-level tracer, a chunk of items at a time, and then, chunk by chunk, this kernel standing by for the
+        // items of chunks that were given up.
+        const uint32_t capacity = wavefront != nullptr && wavefront->mem != nullptr && !exact && wavefront_serves(sc, ra, exact) ? wavefront_capacity(wavefront->bytes) : 0u;
+        if (capacity != 0u) {
+            const double per_item = wavefront->nodes_per_item > 0.0 ? wavefront->nodes_per_item : 24.0;
+            uint64_t room = (uint64_t)((double)capacity / (per_item * 1.3));
+            if (room > capacity / 2u) room = capacity / 2u;
+            const uint64_t n_chunks = room >= 4096u ? ((uint64_t)ra.n_items + room - 1u) / room : (uint64_t)WAVEFRONT_MAX_CHUNKS + 1u;
+            if (n_chunks <= WAVEFRONT_MAX_CHUNKS) {
+                const uint32_t per_chunk = (uint32_t)((((uint64_t)ra.n_items + n_chunks - 1u) / n_chunks + 63u) & ~(uint64_t)63u);
+                if (tune.mode == WALK_TUNE_CALIBRATE) tune.mode = WALK_TUNE_LONG;
+                RenderArgs rw = ra;
+                set_item_order(rw, 0u);   // every sample block by block: nothing there needs the deep trees spread out
+                if ((e = hipMemsetAsync(wavefront->mem, 0, (size_t)n_chunks * sizeof(uint32_t), stream)) != hipSuccess) return e;
+                uint32_t chunk_index = 0u;
+                for (uint32_t item0 = 0u; item0 < ra.n_items; item0 += per_chunk, chunk_index++) {
+                    const uint32_t item1 = ra.n_items - item0 < per_chunk ? ra.n_items : item0 + per_chunk;
+                    e = launch_wavefront_chunk(sc, rw, counted, d_samples, d_stats, wavefront->mem, wavefront->bytes, chunk_index, item0, item1, stream);
+                    if (e != hipSuccess) return e;
+                }
+                chunk_index = 0u;
+                for (uint32_t item0 = 0u; item0 < ra.n_items; item0 += per_chunk, chunk_index++) {
+                    const uint32_t item1 = ra.n_items - item0 < per_chunk ? ra.n_items : item0 + per_chunk;
+                    const uint32_t* given_up = wavefront_chunk_flag(wavefront->mem, chunk_index);
+                    e = hipMemsetD32Async(reinterpret_cast<hipDeviceptr_t>(d_work_counter), (int)item0, 1, stream);
+                    if (e != hipSuccess) return e;
+                    RenderArgs rb = rw;     // the same item order: the stand-by kernel must trace exactly the chunk's items
+                    rb.n_items = item1;
+                    if (counted) hipLaunchKernelGGL((mesh_trace_kernel<false, true>), grid, block, 0, stream, sc, rb, s, d_stats, d_work_counter, timeline, slab, tune, chunk, guide, share, steady_depth, given_up);
+                    else hipLaunchKernelGGL((mesh_trace_kernel<false, false>), grid, block, 0, stream, sc, rb, s, d_stats, d_work_counter, timeline, slab, tune, chunk, guide, share, steady_depth, given_up);
+                    if ((e = hipGetLastError()) != hipSuccess) return e;
+                }
+                return hipSuccess;
+            }
+        }
+#define SRT_LAUNCH_MESH(E, C) hipLaunchKernelGGL((mesh_trace_kernel<E, C>), grid, block, 0, stream, sc, ra, s, d_stats, d_work_counter, timeline, slab, tune, chunk, guide, share, steady_depth, (const uint32_t*)nullptr)
         if (exact) { if (counted) SRT_LAUNCH_MESH(true, true); else SRT_LAUNCH_MESH(true, false); }
         else { if (counted) SRT_LAUNCH_MESH(false, true); else SRT_LAUNCH_MESH(false, false); }
 #undef SRT_LAUNCH_MESH

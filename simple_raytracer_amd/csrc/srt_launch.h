@@ -21,9 +21,29 @@ namespace srt {
 // "measure both at the start of the launch and take the faster".  A calibrating launch adds what it measured to d_stats
 // words 12-15 (traversals finished, wall-clock ticks; preset 0 then 1); walk_tune_prefers_short() reads them.
 enum { WALK_TUNE_LONG = 0, WALK_TUNE_SHORT = 1, WALK_TUNE_CALIBRATE = 2 };
+// wavefront: memory for the level-by-level tracer (srt_wavefront.hip), which launch_trace uses for scenes it serves
+// (wavefront_serves) when the pool holds at least a few thousand nodes; nullptr, or a pool without memory: the one-kernel
+// tracers only.  nodes_per_item is the caller's estimate of the node records per work item (0: none yet), from d_stats
+// words kStatsWavefrontNodes / kStatsWavefrontItems of earlier launches; it sizes the chunks of items that share the
+// pool.  A chunk that outgrows the pool all the same is traced by mesh_trace_kernel (kStatsWavefrontGivenUp counts them).
+// (Chunks on two streams, each in its own half of the pool, were measured too: the kernels of the two streams do run at
+// the same time, each at half its speed -- 301 ms against 290 ms for the 10,000-sphere scene -- so the chunks run one
+// after the other.)
+struct WavefrontPool { void* mem = nullptr; size_t bytes = 0; double nodes_per_item = 0.0; };
+// The pool starts with a header: one "given up" word per chunk of a launch, then the control block of the chunk at work.
+enum : uint32_t { WAVEFRONT_LEVELS = 16, WAVEFRONT_LIGHTS = 4, WAVEFRONT_MAX_CHUNKS = 2048, WAVEFRONT_CONTROL_BYTES = 1024,
+                  WAVEFRONT_HEADER_BYTES = WAVEFRONT_MAX_CHUNKS * 4 + WAVEFRONT_CONTROL_BYTES };
+enum { kStatsUnaskedWord = 48, kStatsWavefrontNodes = 49, kStatsWavefrontItems = 50, kStatsWavefrontGivenUp = 51 };
+bool wavefront_serves(const SceneView& sc, const RenderArgs& ra, bool exact);
+uint32_t wavefront_capacity(size_t pool_bytes);                             // nodes a pool of that size holds (0: too small to use)
+const uint32_t* wavefront_chunk_flag(void* pool_mem, uint32_t chunk);       // device address of "chunk `chunk` of the launch was given up"
+// Items [item0, item1) of the pass -- chunk `chunk` of the launch -- traced level by level; queues its kernels on
+// `stream` and waits for nothing.  The caller zeroes the chunk flags.
+hipError_t launch_wavefront_chunk(const SceneView& sc, const RenderArgs& ra, bool counted, float* d_samples, unsigned long long* d_stats,
+                                  void* pool_mem, size_t pool_bytes, uint32_t chunk, uint32_t item0, uint32_t item1, hipStream_t stream);
 hipError_t launch_trace(const SceneView& sc, const RenderArgs& ra, bool exact, bool counted, float* d_samples,
                         unsigned long long* d_stats, uint32_t* d_work_counter, float* d_timeline, void* d_frame_slab, size_t slab_bytes, hipStream_t stream,
-                        int walk_tune = WALK_TUNE_LONG);
+                        int walk_tune = WALK_TUNE_LONG, const WavefrontPool* wavefront = nullptr);
 size_t trace_frame_slab_bytes();
 size_t trace_frame_slab_block_bytes();
 // The decision rule, shared by the kernel and the host: short quanta must finish traversals at least 3 % faster.

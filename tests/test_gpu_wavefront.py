@@ -1,0 +1,143 @@
+"""The level-by-level tracer (csrc/srt_wavefront.hip) against the oracle and against the one-kernel tracer.
+
+Scenes whose tree is walked with a stack switch to it once a render has shown more than SRT_WAVEFRONT_MIN_RAYS rays per
+sample; the tests set that threshold to 0 to run it from the first render, and SRT_WAVEFRONT_POOL_MB to make its node pool
+small.  Both knobs are read per render / per context, so one process can compare the tracers.  Everything it computes
+goes through the same per-node functions as the other kernels: pictures must be equal bit for bit and the ray counts
+must be the oracle's."""
+import numpy as np
+import pytest
+
+import helpers
+import mesh_cases
+import simple_raytracer_amd as srt
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture()
+def forced(monkeypatch):
+    monkeypatch.setenv("SRT_WAVEFRONT_MIN_RAYS", "0")
+
+
+def deep_tree_spec(n=8, spheres=60):
+    """A mesh inside a cloud of half-metallic spheres: diffuse, metal and reflect child at every hit (up to 3,280 nodes per
+    sample at depth 8)."""
+    spec = helpers.mesh_spec(n=n)
+    rng = np.random.default_rng(3)
+    for _ in range(spheres):
+        c = rng.uniform(-3, 3, 3) + np.array([0, 0, -6.0])
+        spec.materials.append((tuple(float(v) for v in rng.uniform(0.3, 1, 3)), 0.5, 0.9, (0, 0, 0)))
+        spec.spheres.append((tuple(float(v) for v in c), float(rng.uniform(0.2, 0.6)), len(spec.materials) - 1))
+    return spec
+
+
+@pytest.mark.parametrize("case", mesh_cases.CASES, ids=[c[0] for c in mesh_cases.CASES])
+def test_mesh_scenes_match_the_oracle(gpu_renderer_factory, oracle, forced, case):
+    r = gpu_renderer_factory()
+    lsb, npx, st, ost = mesh_cases.run(r, oracle, case, counted=True)
+    r.close()
+    _, _, w, h, spp, _, _ = case
+    assert (lsb, npx) == (0, 0)
+    for k in ("rays_path", "rays_shadow", "hit_nodes"):
+        assert st[k] == ost[k], k
+    assert st["wavefront_items"] >= w * h * spp and st["wavefront_given_up"] == 0      # every sample went through it (the count includes padding pixels)
+    assert st["wavefront_nodes"] >= st["rays_path"]                                      # one record per GetRayColor call, plus holes
+    assert st["box_tests"] > 0 and st["tri_tests"] > 0
+
+
+def test_deep_trees_match_the_oracle_and_the_other_tracer(gpu_renderer_factory, oracle, monkeypatch):
+    spec = deep_tree_spec()
+    w, h = 96, 54
+    world, lights, cam = spec.host(w, h)
+    ref, ost = spec.oracle_scene().render(spec.oracle_camera(w, h), w, h, samples=2, max_depth=8, seed=9, world_kind=oracle.WORLD_SURFACELIST)
+    r = gpu_renderer_factory()
+    r.set_scene(world, lights, cam, world_kind=srt.WORLD_SURFACELIST)
+    # default threshold: the first render of a scene goes through the one-kernel tracer and measures the rays per sample
+    first = r.render(w, h, samples=2, max_depth=8, seed=9, counted=True)
+    st1 = r.stats()
+    assert st1["wavefront_items"] == 0 and st1["rays_path"] > 5 * 2 * w * h
+    second = r.render(w, h, samples=2, max_depth=8, seed=9, counted=True)
+    st2 = r.stats()
+    assert st2["wavefront_items"] >= 2 * w * h and st2["wavefront_given_up"] == 0
+    for img, st in ((first, st1), (second, st2)):
+        assert helpers.max_lsb_diff(img, ref) == (0, 0)
+        for k in ("rays_path", "rays_shadow", "hit_nodes"):
+            assert st[k] == ost[k], k
+    # the same traversals, so the same tests (a box test counts once per child box in either tracer)
+    for k in ("box_tests", "sphere_tests", "tri_tests", "rect_tests", "shadow_unasked"):
+        assert st1[k] == st2[k], k
+    # and back: the knob that turns it off
+    monkeypatch.setenv("SRT_NO_WAVEFRONT", "1")
+    third = r.render(w, h, samples=2, max_depth=8, seed=9)
+    assert r.stats()["wavefront_items"] == 0 and np.array_equal(third, ref)
+    r.close()
+
+
+def test_a_pool_that_is_too_small_hands_the_chunk_to_the_other_tracer(gpu_renderer_factory, oracle, forced, monkeypatch):
+    """32 MiB hold about 160,000 node records.  Before anything is known about a scene a chunk is sized for 24 records per
+    sample; these trees need far more, so chunks are given up and traced by the stand-by kernel: the picture and the counts
+    stay the oracle's.  The next render sizes its chunks by what was seen."""
+    monkeypatch.setenv("SRT_WAVEFRONT_POOL_MB", "32")
+    spec = deep_tree_spec(spheres=140)
+    for i in range(len(spec.materials)):     # every surface fully smooth: no branch of a ray tree ends early
+        a, m, s, e = spec.materials[i]
+        spec.materials[i] = (a, 0.5, 1.0, e)
+    w, h = 128, 72
+    world, lights, cam = spec.host(w, h)
+    ref, ost = spec.oracle_scene().render(spec.oracle_camera(w, h), w, h, samples=1, max_depth=8, seed=4, world_kind=oracle.WORLD_SURFACELIST)
+    r = gpu_renderer_factory()
+    r.set_scene(world, lights, cam, world_kind=srt.WORLD_SURFACELIST)
+    img = r.render(w, h, samples=1, max_depth=8, seed=4, counted=True)
+    st = r.stats()
+    assert st["wavefront_given_up"] > 0, st
+    assert helpers.max_lsb_diff(img, ref) == (0, 0)
+    for k in ("rays_path", "rays_shadow", "hit_nodes"):
+        assert st[k] == ost[k], k
+    again = r.render(w, h, samples=1, max_depth=8, seed=4, counted=True)
+    st2 = r.stats()
+    assert np.array_equal(again, img)
+    for k in ("rays_path", "rays_shadow", "hit_nodes"):
+        assert st2[k] == ost[k], k
+    r.close()
+
+
+def test_tiles_passes_and_padding_pixels(gpu_renderer_factory, forced, monkeypatch):
+    """Tile layout with edge tiles (padding pixels are dead nodes), several sample passes (a small sample buffer) and a rank
+    that owns a part of the tiles: the same pixels as the one-kernel tracer."""
+    monkeypatch.setenv("SRT_SAMPLE_BUFFER_MB", "1")
+    W, H = 400, 200          # 13 x 13 tiles, 56 of them (28,672 pixels, 344 KB per sample) for rank 1: two passes of 3 + 2 samples
+    world, lights, cam = mesh_cases.teapot_with_spheres(W, H)
+    kw = dict(samples=5, max_depth=5, seed=11, layout=srt.LAYOUT_TILES, tile_w=32, tile_h=16, rank=1, world_size=3)
+    r = gpu_renderer_factory()
+    r.set_scene(world, lights, cam, world_kind=srt.WORLD_SURFACELIST)
+    a = r.render(W, H, **kw)
+    sa = r.stats()
+    r.close()
+    monkeypatch.setenv("SRT_NO_WAVEFRONT", "1")
+    r = gpu_renderer_factory()
+    r.set_scene(world, lights, cam, world_kind=srt.WORLD_SURFACELIST)
+    b = r.render(W, H, **kw)
+    sb = r.stats()
+    r.close()
+    assert sa["wavefront_items"] > 0 and sb["wavefront_items"] == 0
+    assert np.array_equal(a, b)
+    for k in ("rays_path", "rays_shadow", "hit_nodes"):
+        assert sa[k] == sb[k], k
+
+
+def test_scenes_it_does_not_serve_keep_their_tracer(gpu_renderer_factory, forced):
+    """Reference trees (SRT_WORLD_BVHNODE), debug modes and scenes without lights are not its business."""
+    world, lights, cam = mesh_cases.sphere_mesh(64, 36)
+    r = gpu_renderer_factory()
+    r.set_scene(world, lights, cam, world_kind=srt.WORLD_BVHNODE)
+    r.render(64, 36, samples=1, max_depth=4, seed=1)
+    assert r.stats()["wavefront_items"] == 0
+    r.set_scene(world, lights, cam, world_kind=srt.WORLD_SURFACELIST)
+    r.render(64, 36, samples=1, max_depth=4, seed=1, mode=srt.MODE_NORMAL)
+    assert r.stats()["wavefront_items"] == 0
+    r.render(64, 36, samples=1, max_depth=0, seed=1)
+    assert r.stats()["wavefront_items"] == 0
+    r.render(64, 36, samples=1, max_depth=4, seed=1)
+    assert r.stats()["wavefront_items"] >= 64 * 36
+    r.close()

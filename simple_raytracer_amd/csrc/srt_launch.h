@@ -35,6 +35,7 @@ enum : uint32_t { WAVEFRONT_LEVELS = 16, WAVEFRONT_LIGHTS = 4, WAVEFRONT_MAX_CHU
                   WAVEFRONT_HEADER_BYTES = WAVEFRONT_MAX_CHUNKS * 4 + WAVEFRONT_CONTROL_BYTES };
 enum { kStatsUnaskedWord = 48, kStatsWavefrontNodes = 49, kStatsWavefrontItems = 50, kStatsWavefrontGivenUp = 51 };
 bool wavefront_serves(const SceneView& sc, const RenderArgs& ra, bool exact);
+size_t wavefront_node_bytes();                                              // pool bytes per node record
 uint32_t wavefront_capacity(size_t pool_bytes);                             // nodes a pool of that size holds (0: too small to use)
 const uint32_t* wavefront_chunk_flag(void* pool_mem, uint32_t chunk);       // device address of "chunk `chunk` of the launch was given up"
 // Items [item0, item1) of the pass -- chunk `chunk` of the launch -- traced level by level; queues its kernels on

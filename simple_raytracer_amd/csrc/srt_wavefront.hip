@@ -49,6 +49,7 @@ constexpr int kBlock = 256;
 constexpr int kWaves = kBlock / 64;
 constexpr uint32_t WF_NONE = 0xFFFFFFFFu;   // val.w: the node's value is final
 constexpr uint32_t WF_LIT = 0xFFFFFFFEu;    // val.w: the node was hit and waits for its shading
+constexpr uint32_t kDraw = 1024;            // queries a walking wavefront draws at a time while there are plenty
 constexpr int kGridBlocks = 256 * 4;        // grid of the per-node kernels (they stride over the level)
 
 struct WfControl {
@@ -112,7 +113,16 @@ __device__ __forceinline__ void st(q4* p, q4 v)
 // 9 ns, so a wavefront does not take entries one request at a time: it reserves `grab` entries at once and hands them to
 // its lanes from there.  What is left of a reservation when the next one is made, or when the kernel ends, is marked as
 // holes (the readers of the array skip them).
-struct WaveRange { uint32_t next = 0u, end = 0u; };   // wave-uniform
+struct WaveRange { uint32_t next = 0u, end = 0u, used = 0u, calls = 0u; };   // wave-uniform; used: entries handed out, calls: requests served
+// How much to reserve next: what the inputs the wavefront still has to go through are expected to need, judged by what
+// its inputs needed so far (at least one full request, at most `grab`), so that its last reservation leaves little over.
+__device__ __forceinline__ uint32_t grab_for(uint32_t grab, uint32_t inputs_done, uint32_t outputs_done, uint32_t inputs_left)
+{
+    if (inputs_done < 256u) return grab;
+    const uint32_t expect = (uint32_t)(((unsigned long long)outputs_done * inputs_left) / inputs_done);
+    const uint32_t want = (expect + (expect >> 3) + 63u) & ~63u;
+    return want < grab ? want : grab;
+}
 
 // `count` entries (0..4) for every lane; returns the lane's first entry.  All lanes of the wavefront must call.
 template <class HOLE>
@@ -120,6 +130,8 @@ __device__ __forceinline__ uint32_t wave_reserve(WaveRange& r, uint32_t* counter
 {
     const unsigned long long m1 = __ballot(count >= 1u), m2 = __ballot(count >= 2u), m3 = __ballot(count >= 3u), m4 = __ballot(count >= 4u);
     const uint32_t total = (uint32_t)(__popcll(m1) + __popcll(m2) + __popcll(m3) + __popcll(m4));
+    r.calls++;
+    r.used += total;
     if (total == 0u) return 0u;
     const uint32_t lane = threadIdx.x & 63u;
     if (r.end - r.next < total) {
@@ -208,9 +220,10 @@ __global__ void __launch_bounds__(kBlock, SRT_WAVEFRONT_WALK_WAVES) wf_walk(Scen
     cnt.box_tests = cnt.sphere_tests = cnt.tri_tests = cnt.rect_tests = 0u;
     uint32_t next = 0u, end = 0u;
     bool dry = false;
-    // queries per draw from the cursor: an eighth of a wavefront's share, so that the launch ends evenly
-    uint32_t draw = ((n / (gridDim.x * (uint32_t)kWaves)) / 8u) & ~63u;
-    draw = draw < 64u ? 64u : (draw > 2048u ? 2048u : draw);
+    // Queries per draw from the cursor: kDraw while there is plenty left, then an ever smaller share of what is left (down
+    // to one per lane), so that no wavefront ends the launch with a long range of its own.
+    const uint32_t guide = gridDim.x * (uint32_t)kWaves * 2u;
+    uint32_t draw = n / guide >= kDraw ? kDraw : (n / guide < 64u ? 64u : ((n / guide) & ~63u));
 
     for (;;) {
         unsigned long long idle = __ballot(q == WF_NONE);
@@ -223,6 +236,8 @@ __global__ void __launch_bounds__(kBlock, SRT_WAVEFRONT_WALK_WAVES) wf_walk(Scen
                     if (b >= n) { dry = true; break; }
                     next = b;
                     end = b + draw < n ? b + draw : n;
+                    const uint32_t share = ((n - end) / guide) & ~63u;
+                    draw = share >= kDraw ? kDraw : (share < 64u ? 64u : share);
                 }
                 const uint32_t avail = end - next, want = (uint32_t)__popcll(idle), rank = lanes_below(idle);
                 if (q == WF_NONE && rank < avail) {
@@ -335,7 +350,8 @@ __global__ void __launch_bounds__(kBlock) wf_hit(SceneView sc, RenderArgs ra, Wf
             st(&pool.val[g], mkq(0.0f, 0.0f, 0.0f, bitsf(WF_LIT)));
         }
         const uint32_t count = (uint32_t)__popc(asked);
-        uint32_t at = wave_reserve(queue, &ctrl->shadow_count[level], count, grab, pool.capacity, hole);
+        const uint32_t calls_left = (n - 1u - first) / (gridDim.x * (uint32_t)kBlock) + 1u;
+        uint32_t at = wave_reserve(queue, &ctrl->shadow_count[level], count, grab_for(grab, queue.calls * 64u, queue.used, calls_left * 64u), pool.capacity, hole);
         if (count == 0u) continue;
         if (at > pool.capacity || count > pool.capacity - at) { ctrl->overflow = 1u; continue; }
         for (uint32_t li = 0; li < sc.n_lights; li++) {
@@ -418,7 +434,8 @@ __global__ void __launch_bounds__(kBlock) wf_shade(SceneView sc, RenderArgs ra, 
                 children = 1u + (metal != 0.0f ? 1u : 0u) + (metal != 1.0f ? 1u : 0u);
             }
         }
-        uint32_t at = wave_reserve(nodes, &ctrl->level_count[level + 1u], children, grab, room, hole);
+        const uint32_t calls_left = (n - 1u - first) / (gridDim.x * (uint32_t)kBlock) + 1u;
+        uint32_t at = wave_reserve(nodes, &ctrl->level_count[level + 1u], children, grab_for(grab, nodes.calls * 64u, nodes.used, calls_left * 64u), room, hole);
         if (children == 0u) continue;
         if (at > room || children > room - at) {
             ctrl->overflow = 1u;
@@ -531,6 +548,8 @@ bool wavefront_serves(const SceneView& sc, const RenderArgs& ra, bool exact)
            ra.max_depth >= 1 && ra.max_depth <= (int32_t)WAVEFRONT_LEVELS;
 }
 
+size_t wavefront_node_bytes() { return kArrays * sizeof(q4); }
+
 uint32_t wavefront_capacity(size_t bytes)
 {
     if (bytes < WAVEFRONT_HEADER_BYTES + kArrays * sizeof(q4) * 4096u) return 0u;
@@ -552,7 +571,7 @@ hipError_t launch_wavefront_chunk(const SceneView& sc, const RenderArgs& ra, boo
     hipError_t e = hipMemsetAsync(pool.ctrl, 0, sizeof(WfControl), stream);
     if (e != hipSuccess) return e;
     static const int rounds = std::getenv("SRT_WF_ROUNDS") ? std::atoi(std::getenv("SRT_WF_ROUNDS")) : 4;
-    static const int steps = std::getenv("SRT_WF_STEPS") ? std::atoi(std::getenv("SRT_WF_STEPS")) : 2;
+    static const int steps = std::getenv("SRT_WF_STEPS") ? std::atoi(std::getenv("SRT_WF_STEPS")) : 4;
     static const int refill_knob = std::getenv("SRT_WF_REFILL") ? std::atoi(std::getenv("SRT_WF_REFILL")) : 8;
     const int refill = refill_knob < 1 ? 1 : (refill_knob > 64 ? 64 : refill_knob);
     static uint32_t walk_blocks = 0u;

@@ -221,12 +221,15 @@ def main():
     counts = [0.0, 0.0]  # path rays, shadow rays of the timed steps
     gather_ms, assemble_ms, per_device = [], [], []   # several GPUs, per step (in-library) or from one extra step (one process per GPU)
 
+    timed_stats = {}      # the library's statistics of the last timed step
+
     def step(record=False):
         if tf is None:
             # blocking: kernels (+ gather + assemble) + copy of the frame into pinned host memory
             r._check(r._lib.srt_render(r._ctx, C.byref(p), host.ctypes.data_as(C.c_void_p)))
             if record:
                 st = r.stats()   # collected by the blocking render; no extra wait
+                timed_stats.update(st)
                 device_ms.append(st["kernel_ms"])
                 counts[0] += st["rays_path"]
                 counts[1] += st["rays_shadow"]
@@ -260,6 +263,7 @@ def main():
     rays, shadow = counts
     if tf is not None:
         st = r.stats()     # counters accumulated over the timed launches; kernel_ms is the last launch's
+        timed_stats.update(st)
         rays, shadow = float(st["rays_path"]), float(st["rays_shadow"])
         device_ms.append(st["kernel_ms"])
         # the parts of a step, from one more (untimed) step with HIP events around them on this rank's stream
@@ -332,7 +336,10 @@ def main():
                           "l2_request_gbs": round(d["tcc_req"] * 128.0 / (avg_ms * 1e-3) / 1e9, 1),
                           "l2_frac": round(d["tcc_req"] * 128.0 / (avg_ms * 1e-3) / 1e9 / PEAK_L2_GBS, 4),
                           "l2_hit_rate": round(d["tcc_hit"] / max(1.0, d["tcc_hit"] + d["tcc_miss"]), 3)}
-        kernel = "trace_kernel" if args.config in ("c1", "c2") else "mesh_trace_kernel"
+        # scenes with deep ray trees switch to the level-by-level tracer after their first frame (the warm-up): the timed
+        # steps then consist of its kernels, and the frame's device time is the sum over them
+        level_by_level = bool(timed_stats.get("wavefront_items", 0))
+        kernel = "trace_kernel" if args.config in ("c1", "c2") else ("wf_walk + wf_hit + wf_shade + wf_combine (level-by-level tracer)" if level_by_level else "mesh_trace_kernel")
         roofline.update({"traffic": traffic, "traffic_source": traffic_source, "kernel": kernel + " (+ resolve_kernel) of one frame",
                          "avg_launch_ms": round(avg_ms, 4),
                          "algorithmic_flops_per_launch": aflops, "algorithmic_bytes_per_launch": abytes,
@@ -372,7 +379,9 @@ def main():
                        "devices": info["devices"] if in_library else [device_index], "rccl_ranks": info["rccl_ranks"] if in_library else (world if world > 1 and backend == "nccl" else 0),
                        "path_rays_per_step": total_rays / args.steps, "shadow_rays_per_step": total_shadow / args.steps,
                        "scene_commit_s": round(commit_s, 3), "bvh_nodes": cst["bvh_nodes"], "surfaces": cst["n_prims"],
-                       "walk_tune": cst["walk_tune"]},
+                       "walk_tune": cst["walk_tune"], "tracer": "level-by-level" if level_by_level else "one kernel",
+                       "node_records_per_ray": round(timed_stats.get("wavefront_nodes", 0) / max(1, timed_stats.get("rays_path", 1)), 3) if level_by_level else None,
+                       "chunks_given_up": int(timed_stats.get("wavefront_given_up", 0))},
             "rays_per_step": total_rays / args.steps, "shadow_rays_per_step": total_shadow / args.steps,
             "traversals_per_sec_M": round((total_rays + total_shadow) / elapsed / 1e6, 2),
             "roofline": roofline,

@@ -86,8 +86,8 @@ __device__ __forceinline__ uint32_t lanes_below(unsigned long long mask)
     return __builtin_amdgcn_mbcnt_hi((uint32_t)(mask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mask, 0u));
 }
 __device__ __forceinline__ q4 mkq(float x, float y, float z, float w) { q4 r; r.x = x; r.y = y; r.z = z; r.w = w; return r; }
-// The pool streams through the caches once per kernel; its loads and stores are marked non-temporal so that they do not
-// push the scene (nodes, primitives), which every traversal step reads, out of the L2.
+// Loads and stores of the pool.  -DSRT_WAVEFRONT_NONTEMPORAL (experiments) marks them non-temporal; measured slower
+// (wf_combine reads what the launch before it wrote), so the default is plain accesses.
 typedef float pool_word __attribute__((ext_vector_type(4)));
 __device__ __forceinline__ q4 ld(const q4* p)
 {
@@ -201,9 +201,13 @@ __global__ void __launch_bounds__(kBlock, SRT_WAVEFRONT_WALK_WAVES) wf_walk(Scen
     const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
     uint32_t* my_stack = &lds_stack[wave * (STACK_DEPTH * 64) + lane];
     WfControl* const ctrl = pool.ctrl;
+    // A chunk that outgrew the pool is given up as soon as a kernel notices: entries that could not be written hold
+    // whatever the memory held before, so no later kernel of the chunk may look at the arrays.
+    if (ctrl->overflow != 0u) return;
     uint32_t n = SHADOW ? ctrl->shadow_count[level] : ctrl->level_count[level];
     const uint32_t base = SHADOW ? 0u : ctrl->level_base[level];
-    if (n > pool.capacity - base) n = pool.capacity - base;   // an overflowing chunk: stay inside the arrays
+    if (base >= pool.capacity) return;
+    if (n > pool.capacity - base) n = pool.capacity - base;   // stay inside the arrays whatever the counters say
     if ((blockIdx.x * (uint32_t)kWaves + wave) * 64u >= n) return;   // more wavefronts than draws: no need to touch the cursor
     uint32_t* const cursor = &ctrl->cursor[2u * level + (SHADOW ? 1u : 0u)];
     const float t_min = SHADOW ? 0.001f : 0.01f;
@@ -245,7 +249,8 @@ __global__ void __launch_bounds__(kBlock, SRT_WAVEFRONT_WALK_WAVES) wf_walk(Scen
                     q4 r0, r1;
                     if (SHADOW) { r0 = ld(&pool.sq0[mine]); r1 = ld(&pool.sq1[mine]); tag0 = fbits(r1.z); tag1 = fbits(r1.w); }
                     else { r0 = ld(&pool.ray0[base + mine]); r1 = ld(&pool.ray1[base + mine]); }
-                    const bool hole = SHADOW ? tag1 == WF_NONE : fbits(r1.z) == 0u;   // left over from a reservation / a dead node
+                    // left over from a reservation / a dead node; a query whose node or light is out of range cannot be one of ours
+                    const bool hole = SHADOW ? (tag1 >= WAVEFRONT_LIGHTS || tag0 >= pool.capacity) : fbits(r1.z) == 0u;
                     if (!hole) {
                         q = mine;
                         o = mk3(r0.x, r0.y, r0.z);
@@ -309,7 +314,9 @@ __global__ void __launch_bounds__(kBlock) wf_hit(SceneView sc, RenderArgs ra, Wf
     __shared__ float unit[UNIT_TABLE];
     fill_unit_table(unit);
     WfControl* const ctrl = pool.ctrl;
+    if (ctrl->overflow != 0u) return;      // the chunk is given up (uniform over the launch: set by an earlier kernel)
     const uint32_t base = ctrl->level_base[level];
+    if (base >= pool.capacity) return;
     uint32_t n = ctrl->level_count[level];
     if (n > pool.capacity - base) n = pool.capacity - base;
     // where the next level starts (the shade kernel of this level allocates there)
@@ -378,10 +385,13 @@ __global__ void __launch_bounds__(kBlock) wf_shade(SceneView sc, RenderArgs ra, 
     __shared__ float unit[UNIT_TABLE];
     fill_unit_table(unit);
     WfControl* const ctrl = pool.ctrl;
+    if (ctrl->overflow != 0u) return;      // the chunk is given up
     const uint32_t base = ctrl->level_base[level];
+    if (base >= pool.capacity) return;
     uint32_t n = ctrl->level_count[level];
     if (n > pool.capacity - base) n = pool.capacity - base;
     const uint32_t next_base = ctrl->level_base[level + 1u];
+    if (next_base > pool.capacity) return;
     const uint32_t lane = threadIdx.x & 63u;
     uint32_t rays_shadow = 0u;
     WaveRange nodes;
@@ -471,7 +481,9 @@ __global__ void __launch_bounds__(kBlock) wf_shade(SceneView sc, RenderArgs ra, 
 __global__ void __launch_bounds__(kBlock) wf_combine(SceneView sc, RenderArgs ra, WfPool pool, uint32_t level)
 {
     WfControl* const ctrl = pool.ctrl;
+    if (ctrl->overflow != 0u) return;      // the chunk is given up
     const uint32_t base = ctrl->level_base[level];
+    if (base >= pool.capacity) return;
     uint32_t n = ctrl->level_count[level];
     if (n > pool.capacity - base) n = pool.capacity - base;
     for (uint32_t i = blockIdx.x * (uint32_t)kBlock + threadIdx.x; i < n; i += gridDim.x * (uint32_t)kBlock) {
@@ -500,18 +512,20 @@ __global__ void __launch_bounds__(kBlock) wf_combine(SceneView sc, RenderArgs ra
     }
 }
 
-__global__ void __launch_bounds__(kBlock) wf_finish(WfPool pool, f3* __restrict__ samples, unsigned long long* __restrict__ stats, uint32_t* __restrict__ given_up)
+__global__ void __launch_bounds__(kBlock) wf_finish(WfPool pool, f3* __restrict__ samples, uint32_t n_slots, unsigned long long* __restrict__ stats, uint32_t* __restrict__ given_up)
 {
     WfControl* const ctrl = pool.ctrl;
     if (ctrl->overflow != 0u) {
         if (blockIdx.x == 0u && threadIdx.x == 0u) { *given_up = 1u; atomicAdd(&stats[kStatsWavefrontGivenUp], 1ull); }
         return;
     }
-    const uint32_t n = ctrl->level_count[0];
+    uint32_t n = ctrl->level_count[0];
+    if (n > pool.capacity) n = pool.capacity;
     for (uint32_t i = blockIdx.x * (uint32_t)kBlock + threadIdx.x; i < n; i += gridDim.x * (uint32_t)kBlock) {
         if (fbits(ld(&pool.ray1[i]).z) == 0u) continue;   // a padding pixel
         const q4 v = ld(&pool.val[i]);
-        samples[fbits(ld(&pool.id[i]).x)] = mk3(v.x, v.y, v.z);
+        const uint32_t slot = fbits(ld(&pool.id[i]).x);
+        if (slot < n_slots) samples[slot] = mk3(v.x, v.y, v.z);
     }
     if (blockIdx.x == 0u && threadIdx.x == 0u) {
         for (int k = 0; k < 7; k++) atomicAdd(&stats[k], ctrl->tally[k]);
@@ -600,7 +614,7 @@ hipError_t launch_wavefront_chunk(const SceneView& sc, const RenderArgs& ra, boo
         if (l + 1u >= levels) continue;   // the nodes of the deepest level have no children
         hipLaunchKernelGGL(wf_combine, grid, block, 0, stream, sc, ra, pool, l);
     }
-    hipLaunchKernelGGL(wf_finish, grid, block, 0, stream, pool, reinterpret_cast<f3*>(d_samples), d_stats, reinterpret_cast<uint32_t*>(pool_mem) + chunk);
+    hipLaunchKernelGGL(wf_finish, grid, block, 0, stream, pool, reinterpret_cast<f3*>(d_samples), ra.n_work * ra.sample_count, d_stats, reinterpret_cast<uint32_t*>(pool_mem) + chunk);
     return hipGetLastError();
 }
 

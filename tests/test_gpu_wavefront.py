@@ -102,6 +102,34 @@ def test_a_pool_that_is_too_small_hands_the_chunk_to_the_other_tracer(gpu_render
     r.close()
 
 
+def test_given_up_chunks_never_read_what_they_could_not_write(gpu_renderer_factory, oracle, forced, monkeypatch):
+    """A camera that looks nowhere sends NaN rays: every node has three children and every surface is tested, so 3^6 nodes
+    per sample outgrow a 32 MiB pool at once.  Entries that an overflowing kernel could not write hold whatever the pool
+    held before (here: the records of another scene's render), so the later kernels of such a chunk must not touch the
+    arrays at all; the stand-by kernel traces the chunk.  Found by tools/degenerate_fuzz.py."""
+    monkeypatch.setenv("SRT_WAVEFRONT_POOL_MB", "32")
+    r = gpu_renderer_factory()
+    # fill the pool with the records of an ordinary render
+    spec = deep_tree_spec()
+    r.set_scene(*spec.host(160, 90), world_kind=srt.WORLD_SURFACELIST)
+    r.render(160, 90, samples=2, max_depth=8, seed=2)
+    assert r.stats()["wavefront_items"] > 0
+    nowhere = helpers.mesh_spec(n=6)
+    nowhere.materials = [(a, 0.5, 1.0, e) for a, m, sm, e in nowhere.materials]     # no branch of a ray tree ends early
+    o, _, fov = nowhere.camera
+    nowhere.camera = (o, o, fov)                 # lookAt == position: the camera basis is NaN
+    w, h = 40, 24
+    r.set_scene(*nowhere.host(w, h), world_kind=srt.WORLD_SURFACELIST)
+    img = r.render(w, h, samples=3, max_depth=6, seed=5, counted=True)
+    st = r.stats()
+    ref, ost = nowhere.oracle_scene().render(nowhere.oracle_camera(w, h), w, h, samples=3, max_depth=6, seed=5, world_kind=oracle.WORLD_SURFACELIST)
+    r.close()
+    assert st["wavefront_given_up"] > 0
+    assert helpers.max_lsb_diff(img, ref)[0] <= 1
+    for k in ("rays_path", "rays_shadow", "hit_nodes"):
+        assert st[k] == ost[k], k
+
+
 def test_tiles_passes_and_padding_pixels(gpu_renderer_factory, forced, monkeypatch):
     """Tile layout with edge tiles (padding pixels are dead nodes), several sample passes (a small sample buffer) and a rank
     that owns a part of the tiles: the same pixels as the one-kernel tracer."""

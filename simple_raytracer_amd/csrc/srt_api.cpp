@@ -302,7 +302,7 @@ struct Workspace {
 struct PassSpec { int first_sample = 0, count = 1; bool first = true, last = true; float preview = 0.0f; };
 
 int launch(srt_ctx* c, DeviceState& d, const srt_render_params* p, uint32_t* d_out, size_t capacity, hipStream_t stream, bool counted,
-           int min_passes = 1, int mix_buffers = 0, const Workspace* fixed_ws = nullptr, const PassSpec* one_pass = nullptr)
+           int min_passes = 1, int mix_buffers = 0, const Workspace* fixed_ws = nullptr, const PassSpec* one_pass = nullptr, bool may_wait = false)
 {
     if (!c->committed) return fail(c, SRT_E_STATE, "srt_commit_scene has not been called");
     if (!c->has_camera) return fail(c, SRT_E_STATE, "srt_set_camera has not been called");
@@ -356,7 +356,17 @@ int launch(srt_ctx* c, DeviceState& d, const srt_render_params* p, uint32_t* d_o
         }
     }
     const size_t need_samples = (size_t)(per_pass * per_sample);
-    const bool multi_pass = one_pass ? !(one_pass->first && one_pass->last) : per_pass < (uint64_t)ra.samples;
+    const SceneView view = scene_view(c, d);
+    const bool exact = c->world_kind == SRT_WORLD_BVHNODE;
+    const char* min_rays_knob = std::getenv("SRT_WAVEFRONT_MIN_RAYS");   // read per launch: tests switch tracers inside one process
+    const double min_rays = min_rays_knob ? std::atof(min_rays_knob) : 5.0;
+    // The first render of a scene does not know yet how many rays a sample takes, and a host like the reference's renders
+    // one frame per scene.  A caller that blocks anyway (may_wait) therefore gets the first sample of every pixel through the
+    // one-kernel tracer, the library reads the ray count of that sample (one wait for the stream), and the remaining
+    // samples go to whichever tracer that count calls for.  The picture is the same either way.
+    const bool probe = may_wait && !fixed_ws && !one_pass && mix_buffers == 0 && min_passes <= 1 && d.rays_per_item == 0.0 && min_rays > 0.0 &&
+                       ra.samples >= 2 && wavefront_serves(view, ra, exact);
+    const bool multi_pass = one_pass ? !(one_pass->first && one_pass->last) : (per_pass < (uint64_t)ra.samples || probe);
     Workspace ws;
     if (fixed_ws) {
         ws = *fixed_ws;
@@ -397,12 +407,26 @@ int launch(srt_ctx* c, DeviceState& d, const srt_render_params* p, uint32_t* d_o
         d.launched = true;
         if (!one_pass || one_pass->first) SRT_HIP(c, hipEventRecord(d.ev_begin, stream));
     }
-    const SceneView view = scene_view(c, d);
-    const bool exact = c->world_kind == SRT_WORLD_BVHNODE;
     const WavefrontPool* wavefront = nullptr;
-    const char* min_rays_knob = std::getenv("SRT_WAVEFRONT_MIN_RAYS");   // read per launch: tests switch tracers inside one process
-    const double min_rays = min_rays_knob ? std::atof(min_rays_knob) : 5.0;
-    if (std::getenv("SRT_DEBUG_LAUNCH")) std::fprintf(stderr, "srt: rays per item %.2f (level-by-level tracer from %.2f), serves %d\n", d.rays_per_item, min_rays, (int)wavefront_serves(view, ra, exact));
+    uint32_t first_sample_of_loop = 0u;
+    if (probe) {
+        ra.sample_first = 0u;
+        ra.sample_count = 1u;
+        ra.n_items = ra.n_work;
+        hipError_t e = launch_trace(view, ra, exact, counted, ws.samples, d.d_stats, ws.counter, d.d_timeline, d.d_frame_slab, d.slab_bytes, stream, d.walk_tune, nullptr);
+        d.items_since_collect += ra.n_items;
+        if (e != hipSuccess) return hip_fail(c, e, "trace kernel launch");
+        e = launch_resolve(ra, ws.samples, ws.running, d_out, true, false, 0.0f, stream);
+        if (e != hipSuccess) return hip_fail(c, e, "resolve kernel launch");
+        unsigned long long rays = 0ull;
+        SRT_HIP(c, hipMemcpyAsync(&rays, d.d_stats, sizeof(rays), hipMemcpyDeviceToHost, stream));
+        SRT_HIP(c, hipStreamSynchronize(stream));
+        // the counters may hold earlier launches that were not collected yet: an estimate from above, which only ever
+        // sends a scene to the level-by-level tracer one render early
+        d.rays_per_item = (double)rays / (double)d.items_since_collect;
+        first_sample_of_loop = 1u;
+    }
+    if (std::getenv("SRT_DEBUG_LAUNCH")) std::fprintf(stderr, "srt: rays per item %.2f (level-by-level tracer from %.2f), serves %d, probed %d\n", d.rays_per_item, min_rays, (int)wavefront_serves(view, ra, exact), (int)probe);
     if (!fixed_ws && d.rays_per_item >= min_rays && wavefront_serves(view, ra, exact)) {
         // The pool is sized for what the largest pass of this render is expected to need (so that it is one chunk), within
         // SRT_WAVEFRONT_POOL_MB (default 128 GiB) and 60 % of the memory that is free; it grows when a later render needs
@@ -461,7 +485,7 @@ int launch(srt_ctx* c, DeviceState& d, const srt_render_params* p, uint32_t* d_o
         return SRT_OK;
     }
     int pass = 0;
-    for (uint32_t s0 = 0; s0 < (uint32_t)ra.samples; s0 += (uint32_t)per_pass, pass++) {
+    for (uint32_t s0 = first_sample_of_loop; s0 < (uint32_t)ra.samples; s0 += (uint32_t)per_pass, pass++) {
         ra.sample_first = s0;
         ra.sample_count = (uint32_t)ra.samples - s0 < (uint32_t)per_pass ? (uint32_t)ra.samples - s0 : (uint32_t)per_pass;
         ra.n_items = ra.n_work * ra.sample_count;
@@ -706,7 +730,7 @@ int render_blocking(srt_ctx* c, const srt_render_params* p, uint32_t* rgba_out, 
         src = c->d_frame;
     } else {
         if ((rc = ensure_pixels(c, &d.d_out, &d.out_capacity, (size_t)n)) != SRT_OK) return rc;
-        if ((rc = launch(c, d, p, d.d_out, d.out_capacity, d.stream, counted, 1, mix_buffers)) != SRT_OK) return rc;
+        if ((rc = launch(c, d, p, d.d_out, d.out_capacity, d.stream, counted, 1, mix_buffers, nullptr, nullptr, true)) != SRT_OK) return rc;
         src = d.d_out;
     }
     SRT_HIP(c, hipSetDevice(d.device));

@@ -261,7 +261,12 @@ int  srt_render_device_static(srt_ctx* ctx, const srt_render_params* p, void* d_
 int  srt_render_counted(srt_ctx* ctx, const srt_render_params* p, uint32_t* rgba_out);
 
 /* Replaces the threadArray[i].IsAlive polling of Game1.Update (Game1.cs:188-201): start a render,
- * ask whether it is done, wait for it.  rgba_out must stay valid until done. */
+ * ask whether it is done, wait for it.  rgba_out must stay valid until done.
+ * The first render of a newly committed scene whose tree is walked with a stack may run in two stages: srt_render_async
+ * queues the first sample of every pixel, and the srt_poll (or srt_wait) that finds it finished reads how many rays a
+ * sample of this scene takes, queues the remaining samples for the tracer that suits the count, and reports "not done".
+ * A host that calls srt_poll every frame, as Game1.Update does, notices nothing; one that never polls must call
+ * srt_wait.  The frame is the same either way. */
 int  srt_render_async(srt_ctx* ctx, const srt_render_params* p, uint32_t* rgba_out);
 int  srt_poll(srt_ctx* ctx, int* done);
 int  srt_wait(srt_ctx* ctx);

@@ -143,6 +143,10 @@ struct srt_ctx {
     uint32_t* async_dst = nullptr;
     size_t async_pixels = 0;
     bool async_pending = false;
+    // A new scene's asynchronous render starts with one probe sample per pixel; srt_poll / srt_wait queue the rest once
+    // that sample is done and its ray count says which tracer the scene wants (see launch()).
+    bool async_probing = false;
+    srt_render_params async_params{};
     // progressive render: one event per pass, recorded after the pass's preview reached pinned memory
     enum { MAX_PASSES = 64 };
     hipEvent_t pass_done[MAX_PASSES] = {};
@@ -301,6 +305,21 @@ struct Workspace {
 // resolved into d_out -- added to the running sums unless it is both the first and the last pass.
 struct PassSpec { int first_sample = 0, count = 1; bool first = true, last = true; float preview = 0.0f; };
 
+// Whether the first render of a scene should find out with one sample per pixel which tracer the scene wants.
+static double wavefront_min_rays()
+{
+    const char* knob = std::getenv("SRT_WAVEFRONT_MIN_RAYS");   // read per launch: tests switch tracers inside one process
+    return knob ? std::atof(knob) : 5.0;
+}
+static bool wants_probe(srt_ctx* c, const DeviceState& d, const srt_render_params* p)
+{
+    if (!c->committed || !c->has_camera || c->dev.size() != 1 || d.rays_per_item != 0.0 || wavefront_min_rays() <= 0.0 || p->samples < 2) return false;
+    RenderArgs ra;
+    std::string ignored;
+    if (make_render_args(p, c->cam, ra, ignored) != SRT_OK || ra.n_work == 0u) return false;
+    return wavefront_serves(scene_view(c, d), ra, c->world_kind == SRT_WORLD_BVHNODE);
+}
+
 int launch(srt_ctx* c, DeviceState& d, const srt_render_params* p, uint32_t* d_out, size_t capacity, hipStream_t stream, bool counted,
            int min_passes = 1, int mix_buffers = 0, const Workspace* fixed_ws = nullptr, const PassSpec* one_pass = nullptr, bool may_wait = false)
 {
@@ -334,8 +353,9 @@ int launch(srt_ctx* c, DeviceState& d, const srt_render_params* p, uint32_t* d_o
     }
     if (per_pass > (uint64_t)ra.samples) per_pass = (uint64_t)ra.samples;
     if (one_pass) {
-        if ((uint64_t)one_pass->count > per_pass) return fail(c, SRT_E_LIMIT, "a pass of this size does not fit the sample buffer");
-        per_pass = (uint64_t)one_pass->count;
+        // a span of samples that does not fit the sample buffer is traced in several passes; only its last pass can show a preview
+        if ((uint64_t)one_pass->count > per_pass && one_pass->preview != 0.0f) return fail(c, SRT_E_LIMIT, "a pass of this size does not fit the sample buffer");
+        if ((uint64_t)one_pass->count < per_pass) per_pass = (uint64_t)one_pass->count;
     }
     if (mix_buffers > 0) {
         if (ra.layout != 0 || ra.world_size != 1) return fail(c, SRT_E_INVALID, "the mix-buffer technique renders whole frames (SRT_LAYOUT_FRAME, world_size 1)");
@@ -358,14 +378,12 @@ int launch(srt_ctx* c, DeviceState& d, const srt_render_params* p, uint32_t* d_o
     const size_t need_samples = (size_t)(per_pass * per_sample);
     const SceneView view = scene_view(c, d);
     const bool exact = c->world_kind == SRT_WORLD_BVHNODE;
-    const char* min_rays_knob = std::getenv("SRT_WAVEFRONT_MIN_RAYS");   // read per launch: tests switch tracers inside one process
-    const double min_rays = min_rays_knob ? std::atof(min_rays_knob) : 5.0;
+    const double min_rays = wavefront_min_rays();
     // The first render of a scene does not know yet how many rays a sample takes, and a host like the reference's renders
     // one frame per scene.  A caller that blocks anyway (may_wait) therefore gets the first sample of every pixel through the
     // one-kernel tracer, the library reads the ray count of that sample (one wait for the stream), and the remaining
     // samples go to whichever tracer that count calls for.  The picture is the same either way.
-    const bool probe = may_wait && !fixed_ws && !one_pass && mix_buffers == 0 && min_passes <= 1 && d.rays_per_item == 0.0 && min_rays > 0.0 &&
-                       ra.samples >= 2 && wavefront_serves(view, ra, exact);
+    const bool probe = may_wait && !fixed_ws && !one_pass && mix_buffers == 0 && min_passes <= 1 && wants_probe(c, d, p);
     const bool multi_pass = one_pass ? !(one_pass->first && one_pass->last) : (per_pass < (uint64_t)ra.samples || probe);
     Workspace ws;
     if (fixed_ws) {
@@ -433,7 +451,7 @@ int launch(srt_ctx* c, DeviceState& d, const srt_render_params* p, uint32_t* d_o
         // more and is never shrunk.  Few large chunks matter: the 10,000-sphere scene at 1080p and 16 samples takes
         // 411 ms with 4 GiB (40 chunks), 251 ms with 16 GiB (10) and 198 ms in one chunk.
         const double per_item = d.wavefront.nodes_per_item > 0.0 ? d.wavefront.nodes_per_item : 1.25 * (d.rays_per_item > 4.0 ? d.rays_per_item : 4.0);
-        const uint64_t pass_items = (uint64_t)ra.n_work * (one_pass ? (uint64_t)one_pass->count : (mix_buffers > 0 ? 1u : per_pass));
+        const uint64_t pass_items = (uint64_t)ra.n_work * (mix_buffers > 0 ? 1u : per_pass);
         const double want_nodes = 1.35 * per_item * (double)pass_items;
         size_t want = (size_t)WAVEFRONT_HEADER_BYTES + (size_t)(want_nodes * (double)wavefront_node_bytes());
         size_t cap = (size_t)131072 << 20;
@@ -470,14 +488,18 @@ int launch(srt_ctx* c, DeviceState& d, const srt_render_params* p, uint32_t* d_o
         return SRT_OK;
     }
     if (one_pass) {
-        ra.sample_first = (uint32_t)one_pass->first_sample;
-        ra.sample_count = (uint32_t)one_pass->count;
-        ra.n_items = ra.n_work * ra.sample_count;
-        hipError_t e = launch_trace(view, ra, exact, counted, ws.samples, d.d_stats, ws.counter, d.d_timeline, d.d_frame_slab, d.slab_bytes, stream, d.walk_tune, wavefront);
+        const uint32_t span_first = (uint32_t)one_pass->first_sample, span_end = span_first + (uint32_t)one_pass->count;
+        for (uint32_t s0 = span_first; s0 < span_end; s0 += (uint32_t)per_pass) {
+            ra.sample_first = s0;
+            ra.sample_count = span_end - s0 < (uint32_t)per_pass ? span_end - s0 : (uint32_t)per_pass;
+            ra.n_items = ra.n_work * ra.sample_count;
+            hipError_t e = launch_trace(view, ra, exact, counted, ws.samples, d.d_stats, ws.counter, d.d_timeline, d.d_frame_slab, d.slab_bytes, stream, d.walk_tune, wavefront);
             d.items_since_collect += ra.n_items;
-        if (e != hipSuccess) return hip_fail(c, e, "trace kernel launch");
-        e = launch_resolve(ra, ws.samples, ws.running, d_out, one_pass->first, one_pass->last, one_pass->preview, stream);
-        if (e != hipSuccess) return hip_fail(c, e, "resolve kernel launch");
+            if (e != hipSuccess) return hip_fail(c, e, "trace kernel launch");
+            const bool ends = s0 + ra.sample_count >= span_end;
+            e = launch_resolve(ra, ws.samples, ws.running, d_out, one_pass->first && s0 == span_first, one_pass->last && ends, ends ? one_pass->preview : 0.0f, stream);
+            if (e != hipSuccess) return hip_fail(c, e, "resolve kernel launch");
+        }
         if (!recorded) {
             SRT_HIP(c, hipEventRecord(d.ev_end, stream));
             d.stats_pending = true;
@@ -1073,6 +1095,17 @@ static int start_async(srt_ctx* c, const srt_render_params* p, uint32_t* rgba_ou
         SRT_HIP(c, hipSetDevice(d.device));
     } else {
         if ((rc = ensure_pixels(c, &d.d_out, &d.out_capacity, (size_t)n)) != SRT_OK) return rc;
+        if (passes <= 1 && wants_probe(c, d, p)) {
+            // the first sample now; the others when srt_poll / srt_wait find it done
+            const PassSpec probe{0, 1, true, false, 0.0f};
+            if ((rc = launch(c, d, p, d.d_out, d.out_capacity, d.stream, false, 1, 0, nullptr, &probe)) != SRT_OK) return rc;
+            c->async_probing = true;
+            c->async_params = *p;
+            c->async_dst = rgba_out;
+            c->async_pixels = (size_t)n;
+            c->async_pending = true;
+            return SRT_OK;
+        }
         if ((rc = launch(c, d, p, d.d_out, d.out_capacity, d.stream, false, passes)) != SRT_OK) return rc;
         src = d.d_out;
     }
@@ -1082,6 +1115,23 @@ static int start_async(srt_ctx* c, const srt_render_params* p, uint32_t* rgba_ou
     c->async_dst = rgba_out;
     c->async_pixels = (size_t)n;
     c->async_pending = true;
+    return SRT_OK;
+}
+
+// The probe sample of an asynchronous render is done (the caller has seen the stream idle): its ray count, then the
+// other samples and the copy of the frame.
+static int continue_async(srt_ctx* c)
+{
+    DeviceState& d = c->dev[0];
+    SRT_HIP(c, hipSetDevice(d.device));
+    unsigned long long rays = 0ull;
+    SRT_HIP(c, hipMemcpy(&rays, d.d_stats, sizeof(rays), hipMemcpyDeviceToHost));
+    if (d.items_since_collect != 0) d.rays_per_item = (double)rays / (double)d.items_since_collect;
+    c->async_probing = false;
+    const PassSpec rest{1, c->async_params.samples - 1, false, true, 0.0f};
+    int rc = launch(c, d, &c->async_params, d.d_out, d.out_capacity, d.stream, false, 1, 0, nullptr, &rest);
+    if (rc != SRT_OK) { c->async_pending = false; return rc; }
+    SRT_HIP(c, hipMemcpyAsync(c->h_pinned, d.d_out, c->async_pixels * sizeof(uint32_t), hipMemcpyDeviceToHost, d.stream));
     return SRT_OK;
 }
 
@@ -1130,6 +1180,7 @@ int srt_poll(srt_ctx* c, int* done)
     hipError_t e = hipStreamQuery(c->dev[0].stream);
     if (e == hipErrorNotReady) { *done = 0; return SRT_OK; }
     if (e != hipSuccess) return hip_fail(c, e, "hipStreamQuery");
+    if (c->async_probing) { *done = 0; return continue_async(c); }
     *done = 1;
     return finish_async(c);
 }
@@ -1139,6 +1190,11 @@ int srt_wait(srt_ctx* c)
     if (!c) return SRT_E_INVALID;
     if (!c->async_pending) return SRT_OK;
     SRT_HIP(c, hipStreamSynchronize(c->dev[0].stream));
+    if (c->async_probing) {
+        int rc = continue_async(c);
+        if (rc != SRT_OK) return rc;
+        SRT_HIP(c, hipStreamSynchronize(c->dev[0].stream));
+    }
     return finish_async(c);
 }
 

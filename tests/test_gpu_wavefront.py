@@ -131,6 +131,32 @@ def test_given_up_chunks_never_read_what_they_could_not_write(gpu_renderer_facto
         assert st[k] == ost[k], k
 
 
+def test_asynchronous_first_render_switches_after_its_probe_sample(gpu_renderer_factory, oracle):
+    """srt_render_async of a new scene queues one sample per pixel; srt_poll (or srt_wait) finds it done, reads the ray count
+    and queues the other samples for the tracer the count calls for.  The frame is the blocking render's."""
+    import time
+    spec = deep_tree_spec()
+    w, h = 96, 54
+    ref, ost = spec.oracle_scene().render(spec.oracle_camera(w, h), w, h, samples=3, max_depth=8, seed=9, world_kind=oracle.WORLD_SURFACELIST)
+    for use_poll in (True, False):
+        r = gpu_renderer_factory()
+        r.set_scene(*spec.host(w, h), world_kind=srt.WORLD_SURFACELIST)
+        p = r.params(w, h, samples=3, max_depth=8, seed=9)
+        out = np.zeros((h, w), dtype=np.uint32)
+        r.render_async(p, out)
+        if use_poll:
+            deadline = time.time() + 60
+            while not r.poll():
+                assert time.time() < deadline
+                time.sleep(0.001)
+        else:
+            r.wait()
+        st = r.stats()
+        r.close()
+        assert helpers.max_lsb_diff(out, ref) == (0, 0)
+        assert st["wavefront_items"] >= 2 * w * h and st["rays_path"] == ost["rays_path"]       # samples 1 and 2 of every pixel
+
+
 def test_tiles_passes_and_padding_pixels(gpu_renderer_factory, forced, monkeypatch):
     """Tile layout with edge tiles (padding pixels are dead nodes), several sample passes (a small sample buffer) and a rank
     that owns a part of the tiles: the same pixels as the one-kernel tracer."""

@@ -50,7 +50,8 @@ constexpr int kWaves = kBlock / 64;
 constexpr uint32_t WF_NONE = 0xFFFFFFFFu;   // val.w: the node's value is final
 constexpr uint32_t WF_LIT = 0xFFFFFFFEu;    // val.w: the node was hit and waits for its shading
 constexpr uint32_t kDraw = 1024;            // queries a walking wavefront draws at a time while there are plenty
-constexpr int kGridBlocks = 256 * 4;        // grid of the per-node kernels (they stride over the level)
+constexpr int kGridBlocks = 256 * 3;        // grid of the per-node kernels (they stride over the level): 3 blocks per CU, what wf_shade's registers
+                                            // allow (10,000-sphere frame: 1024 blocks 181.0 ms, 896 186.8, 768 177.8, 640 186.0, 512 189.7)
 
 struct WfControl {
     uint32_t level_base[WAVEFRONT_LEVELS + 1];
@@ -309,7 +310,10 @@ __device__ __forceinline__ void load_node(const WfPool& pool, uint32_t g, const 
 }
 
 // Closest-hit queries that are answered (lane_on_closest), and the shadow queries of the hits.
-__global__ void __launch_bounds__(kBlock) wf_hit(SceneView sc, RenderArgs ra, WfPool pool, uint32_t level)
+#ifndef SRT_WF_HIT_WAVES
+#define SRT_WF_HIT_WAVES 4
+#endif
+__global__ void __launch_bounds__(kBlock, SRT_WF_HIT_WAVES) wf_hit(SceneView sc, RenderArgs ra, WfPool pool, uint32_t level)
 {
     __shared__ float unit[UNIT_TABLE];
     fill_unit_table(unit);
@@ -380,7 +384,10 @@ __global__ void __launch_bounds__(kBlock) wf_hit(SceneView sc, RenderArgs ra, Wf
 }
 
 // The lights of the hit nodes, their shading, and their children: the nodes of the next level.
-__global__ void __launch_bounds__(kBlock) wf_shade(SceneView sc, RenderArgs ra, WfPool pool, uint32_t level)
+#ifndef SRT_WF_SHADE_WAVES
+#define SRT_WF_SHADE_WAVES 3
+#endif
+__global__ void __launch_bounds__(kBlock, SRT_WF_SHADE_WAVES) wf_shade(SceneView sc, RenderArgs ra, WfPool pool, uint32_t level)
 {
     __shared__ float unit[UNIT_TABLE];
     fill_unit_table(unit);
@@ -597,7 +604,8 @@ hipError_t launch_wavefront_chunk(const SceneView& sc, const RenderArgs& ra, boo
         else walk_blocks = 1024u;
         if (std::getenv("SRT_DEBUG_LAUNCH")) std::fprintf(stderr, "srt: wavefront walkers: %u resident blocks\n", walk_blocks);
     }
-    const dim3 block(kBlock), grid(kGridBlocks), walkers(walk_blocks);
+    static const int grid_knob = std::getenv("SRT_WF_GRID") ? std::atoi(std::getenv("SRT_WF_GRID")) : kGridBlocks;
+    const dim3 block(kBlock), grid(grid_knob > 0 ? grid_knob : kGridBlocks), walkers(walk_blocks);
     const uint32_t n_items = item1 - item0;
     const uint32_t gen_blocks = (n_items + kBlock - 1) / kBlock;
     hipLaunchKernelGGL(wf_generate, dim3(gen_blocks < (uint32_t)kGridBlocks ? gen_blocks : (uint32_t)kGridBlocks), block, 0, stream, ra, pool, item0, item1);

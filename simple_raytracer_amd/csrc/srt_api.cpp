@@ -453,7 +453,7 @@ int launch(srt_ctx* c, DeviceState& d, const srt_render_params* p, uint32_t* d_o
         const double per_item = d.wavefront.nodes_per_item > 0.0 ? d.wavefront.nodes_per_item : 1.25 * (d.rays_per_item > 4.0 ? d.rays_per_item : 4.0);
         const uint64_t pass_items = (uint64_t)ra.n_work * (mix_buffers > 0 ? 1u : per_pass);
         const double want_nodes = 1.35 * per_item * (double)pass_items;
-        size_t want = (size_t)WAVEFRONT_HEADER_BYTES + (size_t)(want_nodes * (double)wavefront_node_bytes());
+        size_t want = wavefront_header_bytes() + (size_t)(want_nodes * (double)wavefront_node_bytes());
         size_t cap = (size_t)131072 << 20;
         if (const char* mb = std::getenv("SRT_WAVEFRONT_POOL_MB")) cap = (size_t)std::atoll(mb) << 20;
         if (want > cap) want = cap;
@@ -465,6 +465,12 @@ int launch(srt_ctx* c, DeviceState& d, const srt_render_params* p, uint32_t* d_o
             if (hipMemGetInfo(&free_b, &total_b) == hipSuccess && want > free_b / 10 * 6) { want = free_b / 10 * 6; d.wavefront_full = true; }
             if (wavefront_capacity(want) != 0u && hipMalloc(&d.wavefront.mem, want) == hipSuccess) d.wavefront.bytes = want;
             else { d.wavefront.mem = nullptr; d.wavefront_full = true; (void)hipGetLastError(); }
+            if (d.wavefront.mem && !d.wavefront.far_stacks && wavefront_far_stack_bytes() != 0 &&
+                hipMalloc(&d.wavefront.far_stacks, wavefront_far_stack_bytes()) != hipSuccess) {
+                (void)hipGetLastError();
+                (void)hipFree(d.wavefront.mem);
+                d.wavefront.mem = nullptr; d.wavefront.bytes = 0; d.wavefront.far_stacks = nullptr; d.wavefront_full = true;
+            }
         }
         if (d.wavefront.mem) wavefront = &d.wavefront;
     }
@@ -796,6 +802,7 @@ void destroy_device(DeviceState& d)
     if (d.d_counter) hipFree(d.d_counter);
     if (d.d_timeline) hipFree(d.d_timeline);
     if (d.wavefront.mem) hipFree(d.wavefront.mem);
+    if (d.wavefront.far_stacks) hipFree(d.wavefront.far_stacks);
     if (d.d_frame_slab) hipFree(d.d_frame_slab);
     if (d.d_samples) hipFree(d.d_samples);
     if (d.d_running) hipFree(d.d_running);

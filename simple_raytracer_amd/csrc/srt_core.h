@@ -465,12 +465,24 @@ SRT_HD bool box_hit_reference(q4 n0, q4 n1, f3 o, f3 inv)
 // walked by trav_begin() / trav_run() below, with the per-lane stack in `stack_mem` at element stride STRIDE (an
 // LDS column on the GPU).
 // ------------------------------------------------------------------------------------------
-template <int STRIDE>
+// NEAR < STACK_DEPTH: only the first NEAR entries live in `base` (an LDS column: less LDS per wavefront, more wavefronts
+// per SIMD); deeper entries, which few traversals ever reach, go to `far` (a column of device memory, same stride).
+template <int STRIDE, int NEAR = STACK_DEPTH>
 struct LaneStack {
     uint32_t* base;
+    uint32_t* far;
     int sp;
-    SRT_HD void push(uint32_t v) { base[sp * STRIDE] = v; sp++; }
-    SRT_HD uint32_t pop() { sp--; return base[sp * STRIDE]; }
+    SRT_HD void push(uint32_t v)
+    {
+        if (NEAR >= STACK_DEPTH || sp < NEAR) base[sp * STRIDE] = v;
+        else far[(sp - NEAR) * STRIDE] = v;
+        sp++;
+    }
+    SRT_HD uint32_t pop()
+    {
+        sp--;
+        return (NEAR >= STACK_DEPTH || sp < NEAR) ? base[sp * STRIDE] : far[(sp - NEAR) * STRIDE];
+    }
 };
 
 template <bool EXACT, bool COUNT>
@@ -602,12 +614,13 @@ SRT_HD void trav_begin(const SceneView& sc, f3 o, float t_min, Trav& tr, uint32_
 
 // PAD: widen every box by tr.pad on all sides (queries that start far outside the scene, see trav_begin).
 // trav_run_with: the caller keeps a = |d|^2 and inv = 1 / d across calls (a kernel that resumes a traversal many times).
-template <bool EXACT, bool COUNT, int STRIDE, bool PAD = false>
-SRT_HD void trav_run_with(const SceneView& sc, f3 o, float a, f3 inv, float t_min, Trav& tr, uint32_t* stack_mem, Counters& cnt, int rounds, int steps)
+template <bool EXACT, bool COUNT, int STRIDE, bool PAD = false, int NEAR = STACK_DEPTH>
+SRT_HD void trav_run_with(const SceneView& sc, f3 o, float a, f3 inv, float t_min, Trav& tr, uint32_t* stack_mem, Counters& cnt, int rounds, int steps,
+                          uint32_t* far_stack = nullptr)
 {
     const f3 d = tr.d;
-    LaneStack<STRIDE> st;
-    st.base = stack_mem; st.sp = tr.sp;
+    LaneStack<STRIDE, NEAR> st;
+    st.base = stack_mem; st.far = far_stack; st.sp = tr.sp;
     Hit best = tr.best;
     uint32_t cur = tr.cur;
     for (int r = 0; r < rounds && cur != TRAV_NONE; r++) {

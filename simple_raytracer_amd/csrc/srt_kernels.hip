@@ -968,7 +968,7 @@ hipError_t launch_trace(const SceneView& sc, const RenderArgs& ra_in, bool exact
                 uint32_t chunk_index = 0u;
                 for (uint32_t item0 = 0u; item0 < ra.n_items; item0 += per_chunk, chunk_index++) {
                     const uint32_t item1 = ra.n_items - item0 < per_chunk ? ra.n_items : item0 + per_chunk;
-                    e = launch_wavefront_chunk(sc, rw, counted, d_samples, d_stats, wavefront->mem, wavefront->bytes, chunk_index, item0, item1, stream);
+                    e = launch_wavefront_chunk(sc, rw, counted, d_samples, d_stats, wavefront->mem, wavefront->bytes, wavefront->far_stacks, chunk_index, item0, item1, stream);
                     if (e != hipSuccess) return e;
                 }
                 chunk_index = 0u;

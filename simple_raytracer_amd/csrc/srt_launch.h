@@ -29,10 +29,13 @@ enum { WALK_TUNE_LONG = 0, WALK_TUNE_SHORT = 1, WALK_TUNE_CALIBRATE = 2 };
 // (Chunks on two streams, each in its own half of the pool, were measured too: the kernels of the two streams do run at
 // the same time, each at half its speed -- 301 ms against 290 ms for the 10,000-sphere scene -- so the chunks run one
 // after the other.)
-struct WavefrontPool { void* mem = nullptr; size_t bytes = 0; double nodes_per_item = 0.0; };
+// far_stacks: wavefront_far_stack_bytes() of device memory, where the traversal kernels keep the far ends of their lanes'
+// stacks (the near ends are in LDS); contents need not survive a launch.
+struct WavefrontPool { void* mem = nullptr; size_t bytes = 0; double nodes_per_item = 0.0; void* far_stacks = nullptr; };
 // The pool starts with a header: one "given up" word per chunk of a launch, then the control block of the chunk at work.
-enum : uint32_t { WAVEFRONT_LEVELS = 16, WAVEFRONT_LIGHTS = 4, WAVEFRONT_MAX_CHUNKS = 2048, WAVEFRONT_CONTROL_BYTES = 1024,
-                  WAVEFRONT_HEADER_BYTES = WAVEFRONT_MAX_CHUNKS * 4 + WAVEFRONT_CONTROL_BYTES };
+enum : uint32_t { WAVEFRONT_LEVELS = 16, WAVEFRONT_LIGHTS = 4, WAVEFRONT_MAX_CHUNKS = 2048, WAVEFRONT_CONTROL_BYTES = 1024, WAVEFRONT_MAX_WALK_BLOCKS = 4096 };
+size_t wavefront_header_bytes();
+size_t wavefront_far_stack_bytes();
 enum { kStatsUnaskedWord = 48, kStatsWavefrontNodes = 49, kStatsWavefrontItems = 50, kStatsWavefrontGivenUp = 51 };
 bool wavefront_serves(const SceneView& sc, const RenderArgs& ra, bool exact);
 size_t wavefront_node_bytes();                                              // pool bytes per node record
@@ -41,7 +44,7 @@ const uint32_t* wavefront_chunk_flag(void* pool_mem, uint32_t chunk);       // d
 // Items [item0, item1) of the pass -- chunk `chunk` of the launch -- traced level by level; queues its kernels on
 // `stream` and waits for nothing.  The caller zeroes the chunk flags.
 hipError_t launch_wavefront_chunk(const SceneView& sc, const RenderArgs& ra, bool counted, float* d_samples, unsigned long long* d_stats,
-                                  void* pool_mem, size_t pool_bytes, uint32_t chunk, uint32_t item0, uint32_t item1, hipStream_t stream);
+                                  void* pool_mem, size_t pool_bytes, void* far_stacks, uint32_t chunk, uint32_t item0, uint32_t item1, hipStream_t stream);
 hipError_t launch_trace(const SceneView& sc, const RenderArgs& ra, bool exact, bool counted, float* d_samples,
                         unsigned long long* d_stats, uint32_t* d_work_counter, float* d_timeline, void* d_frame_slab, size_t slab_bytes, hipStream_t stream,
                         int walk_tune = WALK_TUNE_LONG, const WavefrontPool* wavefront = nullptr);

@@ -37,8 +37,16 @@
 #include "srt_launch.h"
 #include "srt_path.h"
 
+// The walkers want wavefronts: with the whole 36-entry traversal stack in LDS (9 KB per wavefront) a CU holds 4 per SIMD,
+// and 3 instead of 4 costs 13 % (10,000-sphere frame: 202 against 178 ms).  So only the near end of a lane's stack lives
+// in LDS and the far end, which few traversals reach, in a column of device memory (LaneStack<STRIDE, NEAR>).  Measured,
+// same frame: 36 entries / 4 wavefronts 177.2 ms; 28 / 5 170.9; 24 / 6 162.6; 20 / 6 162.8; 20 / 7 158.4; 20 / 8 157.4;
+// 16 / 6 161.4; 16 / 8 156.3 (8 is what a SIMD takes; the kernel then has 64 registers and spills a dozen).
 #ifndef SRT_WAVEFRONT_WALK_WAVES
-#define SRT_WAVEFRONT_WALK_WAVES 4   // wavefronts per SIMD of the walkers (their LDS stacks allow no more)
+#define SRT_WAVEFRONT_WALK_WAVES 8
+#endif
+#ifndef SRT_WAVEFRONT_NEAR_STACK
+#define SRT_WAVEFRONT_NEAR_STACK 16   // entries of a walker's traversal stack that live in LDS; the rest in device memory
 #endif
 
 namespace srt {
@@ -74,8 +82,11 @@ struct WfPool {
     q4 *ray0, *ray1, *id, *hit, *pn0, *pn1, *sh0, *sh1, *fr0, *fr1, *val, *sq0, *sq1;
     uint32_t capacity;
     WfControl* ctrl;
+    uint32_t* far_stacks;    // walkers whose LDS holds only the near end of the traversal stack: the rest, per wavefront of the grid
 };
 constexpr size_t kArrays = 13;
+constexpr size_t kFarStackBytes = (size_t)WAVEFRONT_MAX_WALK_BLOCKS * kWaves * (size_t)(STACK_DEPTH - SRT_WAVEFRONT_NEAR_STACK) * 64u * sizeof(uint32_t);
+constexpr size_t kHeaderBytes = (size_t)WAVEFRONT_MAX_CHUNKS * 4u + WAVEFRONT_CONTROL_BYTES;
 
 __device__ __forceinline__ unsigned long long wave_sum(unsigned long long v)
 {
@@ -198,9 +209,12 @@ __global__ void __launch_bounds__(kBlock) wf_generate(RenderArgs ra, WfPool pool
 template <bool SHADOW, bool COUNT>
 __global__ void __launch_bounds__(kBlock, SRT_WAVEFRONT_WALK_WAVES) wf_walk(SceneView sc, WfPool pool, uint32_t level, int rounds, int steps, int refill)
 {
-    __shared__ uint32_t lds_stack[kWaves * STACK_DEPTH * 64];
+    constexpr int kNear = SRT_WAVEFRONT_NEAR_STACK;
+    __shared__ uint32_t lds_stack[kWaves * kNear * 64];
     const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
-    uint32_t* my_stack = &lds_stack[wave * (STACK_DEPTH * 64) + lane];
+    uint32_t* my_stack = &lds_stack[wave * (kNear * 64) + lane];
+    // the deep end of the stack, if the LDS does not hold all of it: a column per lane of every wavefront of the grid
+    uint32_t* far_stack = kNear < STACK_DEPTH ? pool.far_stacks + ((size_t)(blockIdx.x * (uint32_t)kWaves + wave) * (size_t)(STACK_DEPTH - kNear)) * 64u + lane : nullptr;
     WfControl* const ctrl = pool.ctrl;
     // A chunk that outgrew the pool is given up as soon as a kernel notices: entries that could not be written hold
     // whatever the memory held before, so no later kernel of the chunk may look at the arrays.
@@ -270,8 +284,8 @@ __global__ void __launch_bounds__(kBlock, SRT_WAVEFRONT_WALK_WAVES) wf_walk(Scen
         // queries that start far outside the scene test widened boxes; a wavefront without one keeps the plain walk
         const bool padded = __ballot(active && tr.pad != 0.0f) != 0ull;
         if (active && tr.cur != TRAV_NONE) {
-            if (padded) trav_run_with<false, COUNT, 64, true>(sc, o, a, inv, t_min, tr, my_stack, cnt, rounds, steps);
-            else trav_run_with<false, COUNT, 64>(sc, o, a, inv, t_min, tr, my_stack, cnt, rounds, steps);
+            if (padded) trav_run_with<false, COUNT, 64, true, kNear>(sc, o, a, inv, t_min, tr, my_stack, cnt, rounds, steps, far_stack);
+            else trav_run_with<false, COUNT, 64, false, kNear>(sc, o, a, inv, t_min, tr, my_stack, cnt, rounds, steps, far_stack);
         }
         if (active && tr.cur == TRAV_NONE) {
             if (SHADOW) {
@@ -549,8 +563,9 @@ WfPool carve(void* mem, size_t bytes)
     WfPool p;
     char* at = reinterpret_cast<char*>(mem);
     p.ctrl = reinterpret_cast<WfControl*>(at + WAVEFRONT_MAX_CHUNKS * 4u);
-    at += WAVEFRONT_HEADER_BYTES;
-    const size_t cap = (bytes - WAVEFRONT_HEADER_BYTES) / (kArrays * sizeof(q4));
+    p.far_stacks = nullptr;
+    at += kHeaderBytes;
+    const size_t cap = (bytes - kHeaderBytes) / (kArrays * sizeof(q4));
     p.capacity = cap > 0x7FFFFFF0ull ? 0x7FFFFFF0u : (uint32_t)cap;
     q4** field[kArrays] = {&p.ray0, &p.ray1, &p.id, &p.hit, &p.pn0, &p.pn1, &p.sh0, &p.sh1, &p.fr0, &p.fr1, &p.val, &p.sq0, &p.sq1};
     for (size_t k = 0; k < kArrays; k++) {
@@ -570,10 +585,12 @@ bool wavefront_serves(const SceneView& sc, const RenderArgs& ra, bool exact)
 }
 
 size_t wavefront_node_bytes() { return kArrays * sizeof(q4); }
+size_t wavefront_header_bytes() { return kHeaderBytes; }
+size_t wavefront_far_stack_bytes() { return kFarStackBytes; }
 
 uint32_t wavefront_capacity(size_t bytes)
 {
-    if (bytes < WAVEFRONT_HEADER_BYTES + kArrays * sizeof(q4) * 4096u) return 0u;
+    if (bytes < kHeaderBytes + kArrays * sizeof(q4) * 4096u) return 0u;
     return carve(nullptr, bytes).capacity;
 }
 
@@ -583,11 +600,12 @@ const uint32_t* wavefront_chunk_flag(void* pool_mem, uint32_t chunk)
 }
 
 hipError_t launch_wavefront_chunk(const SceneView& sc, const RenderArgs& ra, bool counted, float* d_samples, unsigned long long* d_stats,
-                                  void* pool_mem, size_t pool_bytes, uint32_t chunk, uint32_t item0, uint32_t item1, hipStream_t stream)
+                                  void* pool_mem, size_t pool_bytes, void* far_stacks, uint32_t chunk, uint32_t item0, uint32_t item1, hipStream_t stream)
 {
     if (item1 <= item0) return hipSuccess;
-    if (chunk >= WAVEFRONT_MAX_CHUNKS) return hipErrorInvalidValue;
-    const WfPool pool = carve(pool_mem, pool_bytes);
+    if (chunk >= WAVEFRONT_MAX_CHUNKS || (kFarStackBytes != 0 && far_stacks == nullptr)) return hipErrorInvalidValue;
+    WfPool pool = carve(pool_mem, pool_bytes);
+    pool.far_stacks = reinterpret_cast<uint32_t*>(far_stacks);
     if (pool.capacity < item1 - item0) return hipErrorInvalidValue;
     hipError_t e = hipMemsetAsync(pool.ctrl, 0, sizeof(WfControl), stream);
     if (e != hipSuccess) return e;
@@ -598,10 +616,12 @@ hipError_t launch_wavefront_chunk(const SceneView& sc, const RenderArgs& ra, boo
     static uint32_t walk_blocks = 0u;
     if (walk_blocks == 0u) {
         int per_cu = 0, dev = 0, cus = 0;
+        walk_blocks = 1024u;
         if (hipGetDevice(&dev) == hipSuccess && hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess &&
             hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, wf_walk<false, false>, kBlock, 0) == hipSuccess && per_cu > 0 && cus > 0)
             walk_blocks = (uint32_t)per_cu * (uint32_t)cus;
-        else walk_blocks = 1024u;
+        if (const char* knob = std::getenv("SRT_WF_WALK_BLOCKS")) walk_blocks = std::atoi(knob) > 0 ? (uint32_t)std::atoi(knob) : walk_blocks;   // experiments
+        if (walk_blocks > WAVEFRONT_MAX_WALK_BLOCKS) walk_blocks = WAVEFRONT_MAX_WALK_BLOCKS;   // the far stacks are sized for that many
         if (std::getenv("SRT_DEBUG_LAUNCH")) std::fprintf(stderr, "srt: wavefront walkers: %u resident blocks\n", walk_blocks);
     }
     static const int grid_knob = std::getenv("SRT_WF_GRID") ? std::atoi(std::getenv("SRT_WF_GRID")) : kGridBlocks;

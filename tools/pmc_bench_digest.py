@@ -33,7 +33,7 @@ def main():
         lines.append(k)
         for c in sorted(v):
             lines.append("   %-26s %.5g per launch (%d launches)" % (c, v[c] / calls[k][c], calls[k][c]))
-        if "SQ_THREAD_CYCLES_VALU" in v and "SQ_ACTIVE_INST_VALU" in v:
+        if v.get("SQ_ACTIVE_INST_VALU", 0) > 0 and v.get("SQ_WAVE_CYCLES", 0) > 0 and "SQ_THREAD_CYCLES_VALU" in v:
             lines.append("   lane utilisation (THREAD_CYCLES_VALU / (ACTIVE_INST_VALU * 64)) = %.3f" % (v["SQ_THREAD_CYCLES_VALU"] / (v["SQ_ACTIVE_INST_VALU"] * 64)))
             lines.append("   VALU issue share of a wave's cycles = %.3f, waiting share = %.3f" % (v["SQ_ACTIVE_INST_VALU"] / v["SQ_WAVE_CYCLES"], v["SQ_WAIT_ANY"] / v["SQ_WAVE_CYCLES"]))
         # the frame's trace kernel: the non-counting instantiation with the most launches

@@ -22,7 +22,8 @@ def main():
     tot = collections.defaultdict(lambda: collections.defaultdict(float))
     calls = collections.defaultdict(lambda: collections.defaultdict(int))
     for i in (1, 2, 3):
-        for f in glob.glob(base + "%d/**/*counter_collection.csv" % i, recursive=True):
+        # gpurun merges every run's files into the same directories: only the newest run's file counts
+        for f in sorted(glob.glob(base + "%d/**/*counter_collection.csv" % i, recursive=True), key=os.path.getmtime)[-1:]:
             for r in csv.DictReader(open(f)):
                 k = r["Kernel_Name"].replace("(anonymous namespace)::", "").split("(")[0]
                 tot[k][r["Counter_Name"]] += float(r["Counter_Value"])
@@ -40,14 +41,15 @@ def main():
         args = k.split("<")[1].rstrip(">").split(",") if "trace_kernel<" in k else []
         if len(args) >= 2 and args[1].strip() == "false" and calls[k].get("FETCH_SIZE", 0) > main_calls:
             main_kernel, main_calls = k, calls[k]["FETCH_SIZE"]
-    # Scenes with deep ray trees: the warm-up frame goes through mesh_trace_kernel, every later frame through the kernels of
-    # the level-by-level tracer (wf_*).  Their counters are summed over all of those kernels; the counting render at the end
-    # (a 16-spp frame) shares the kernels that do no traversal, so it counts as 16 / spp of a frame.
+    # Scenes with deep ray trees: the first sample of the warm-up frame goes through mesh_trace_kernel (the probe), everything
+    # after it through the kernels of the level-by-level tracer (wf_*).  Their counters are summed over all of those kernels;
+    # the counting render at the end (a 16-spp frame) shares the kernels that do no traversal, so it counts as 16 / spp of a
+    # frame, and the warm-up frame as (spp - 1) / spp.
     wf = [k for k in tot if "wf_" in k and calls[k].get("FETCH_SIZE", 0) > 0]
     if any("wf_walk" in k for k in wf) and sum(calls[k]["FETCH_SIZE"] for k in wf) > 8 * main_calls:
         sys.path.insert(0, ROOT)
         spp = {"c3": 64, "c4": 256, "c5": 1024}.get(config, 16)
-        frames = steps + 16.0 / spp
+        frames = steps + (spp - 1.0) / spp + 16.0 / spp
         summed = collections.defaultdict(float)
         for k in wf:
             for c, x in tot[k].items():
@@ -62,7 +64,7 @@ def main():
                  "lane_utilisation_walkers": round(w["SQ_THREAD_CYCLES_VALU"] / (w["SQ_ACTIVE_INST_VALU"] * 64), 3),
                  "source": "profiles/%s_pmc.txt" % label}
         stats = ""
-        for f in glob.glob(base + "trace/**/*kernel_stats.csv", recursive=True):
+        for f in sorted(glob.glob(base + "trace/**/*kernel_stats.csv", recursive=True), key=os.path.getmtime)[-1:]:
             stats = open(f).read()
         with open(os.path.join(ROOT, "profiles", "%s_pmc.txt" % label), "w") as f:
             f.write("python bench.py --config %s --steps %d --warmup 1 --no-cpu-baseline under rocprofv3 (three --pmc passes, one --kernel-trace --stats pass)\n" % (config, steps))
@@ -74,7 +76,7 @@ def main():
         print(json.dumps(entry))
         return
     stats = ""
-    for f in glob.glob(base + "trace/**/*kernel_stats.csv", recursive=True):
+    for f in sorted(glob.glob(base + "trace/**/*kernel_stats.csv", recursive=True), key=os.path.getmtime)[-1:]:
         stats = open(f).read()
     per_frame_frames = steps + 1      # frames rendered by the non-counting kernel in one run: warm-up + timed steps
     v = tot[main_kernel]

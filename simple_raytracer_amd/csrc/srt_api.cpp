@@ -108,6 +108,10 @@ struct DeviceState {
     // levels, so it takes over once this is above SRT_WAVEFRONT_MIN_RAYS (default 5).
     double rays_per_item = 0.0;
     uint64_t items_since_collect = 0;
+    // ... or as soon as one ray tree of SRT_WAVEFRONT_MIN_TREE (default 32) calls was seen: a deep tree is walked by one lane,
+    // node after node, and thirty small glossy spheres beside a mesh (1.57 rays per sample) already make the one-kernel
+    // tracer's frame 38.6 ms instead of 9.0, against 16.9 ms level by level.
+    uint64_t largest_tree = 0;
 };
 
 }  // namespace
@@ -259,6 +263,7 @@ int collect_stats(srt_ctx* c)
         p.wavefront_items = s[kStatsWavefrontItems]; p.wavefront_nodes = s[kStatsWavefrontNodes]; p.wavefront_given_up = s[kStatsWavefrontGivenUp];
         if (d.items_since_collect != 0) d.rays_per_item = (double)s[0] / (double)d.items_since_collect;
         d.items_since_collect = 0;
+        if (s[kStatsLargestTree] > d.largest_tree) d.largest_tree = s[kStatsLargestTree];
         p.kernel_ms = ms;
         d.stats_pending = false;
         alarm = alarm || s[11] != 0ull;
@@ -436,16 +441,19 @@ int launch(srt_ctx* c, DeviceState& d, const srt_render_params* p, uint32_t* d_o
         if (e != hipSuccess) return hip_fail(c, e, "trace kernel launch");
         e = launch_resolve(ra, ws.samples, ws.running, d_out, true, false, 0.0f, stream);
         if (e != hipSuccess) return hip_fail(c, e, "resolve kernel launch");
-        unsigned long long rays = 0ull;
-        SRT_HIP(c, hipMemcpyAsync(&rays, d.d_stats, sizeof(rays), hipMemcpyDeviceToHost, stream));
+        unsigned long long seen[kStatsWords];
+        SRT_HIP(c, hipMemcpyAsync(seen, d.d_stats, sizeof(seen), hipMemcpyDeviceToHost, stream));
         SRT_HIP(c, hipStreamSynchronize(stream));
         // the counters may hold earlier launches that were not collected yet: an estimate from above, which only ever
         // sends a scene to the level-by-level tracer one render early
-        d.rays_per_item = (double)rays / (double)d.items_since_collect;
+        d.rays_per_item = (double)seen[0] / (double)d.items_since_collect;
+        if (seen[kStatsLargestTree] > d.largest_tree) d.largest_tree = seen[kStatsLargestTree];
         first_sample_of_loop = 1u;
     }
     if (std::getenv("SRT_DEBUG_LAUNCH")) std::fprintf(stderr, "srt: rays per item %.2f (level-by-level tracer from %.2f), serves %d, probed %d\n", d.rays_per_item, min_rays, (int)wavefront_serves(view, ra, exact), (int)probe);
-    if (!fixed_ws && d.rays_per_item >= min_rays && wavefront_serves(view, ra, exact)) {
+    const char* min_tree_knob = std::getenv("SRT_WAVEFRONT_MIN_TREE");
+    const uint64_t min_tree = min_tree_knob ? (uint64_t)std::atoll(min_tree_knob) : 32u;
+    if (!fixed_ws && (d.rays_per_item >= min_rays || (min_rays > 0.0 && d.largest_tree >= min_tree)) && wavefront_serves(view, ra, exact)) {
         // The pool is sized for what the largest pass of this render is expected to need (so that it is one chunk), within
         // SRT_WAVEFRONT_POOL_MB (default 128 GiB) and 60 % of the memory that is free; it grows when a later render needs
         // more and is never shrunk.  Few large chunks matter: the 10,000-sphere scene at 1080p and 16 samples takes
@@ -1009,6 +1017,7 @@ int srt_commit_scene(srt_ctx* c, int world_kind)
         d.wavefront.nodes_per_item = 0.0;
         d.rays_per_item = 0.0;
         d.items_since_collect = 0;
+        d.largest_tree = 0;
         if ((rc = upload(c, c->flat.nodes, &d.d_nodes)) != SRT_OK) return rc;
         if ((rc = upload(c, c->flat.prims, &d.d_prims)) != SRT_OK) return rc;
         if ((rc = upload(c, c->flat.normals, &d.d_normals)) != SRT_OK) return rc;
@@ -1131,9 +1140,10 @@ static int continue_async(srt_ctx* c)
 {
     DeviceState& d = c->dev[0];
     SRT_HIP(c, hipSetDevice(d.device));
-    unsigned long long rays = 0ull;
-    SRT_HIP(c, hipMemcpy(&rays, d.d_stats, sizeof(rays), hipMemcpyDeviceToHost));
-    if (d.items_since_collect != 0) d.rays_per_item = (double)rays / (double)d.items_since_collect;
+    unsigned long long seen[kStatsWords];
+    SRT_HIP(c, hipMemcpy(seen, d.d_stats, sizeof(seen), hipMemcpyDeviceToHost));
+    if (d.items_since_collect != 0) d.rays_per_item = (double)seen[0] / (double)d.items_since_collect;
+    if (seen[kStatsLargestTree] > d.largest_tree) d.largest_tree = seen[kStatsLargestTree];
     c->async_probing = false;
     const PassSpec rest{1, c->async_params.samples - 1, false, true, 0.0f};
     int rc = launch(c, d, &c->async_params, d.d_out, d.out_capacity, d.stream, false, 1, 0, nullptr, &rest);

@@ -575,6 +575,9 @@ __global__ void __launch_bounds__(kBlock, SRT_WAVES_PER_SIMD_MESH) mesh_trace_ke
     uint32_t* my_pair = &lds_pair[wave * 64];
     uint32_t handed = 0u;
     uint32_t stalled = 0u;     // wave-uniform: trips in a row in which no lane had anything to run
+    // The largest ray tree this lane finished, in GetRayColor calls (subtrees that went to other lanes are not in it): one
+    // deep tree is milliseconds of one lane's time, and the host sends scenes that have them to the level-by-level tracer.
+    uint32_t item_rays_base = 0u, largest_tree = 0u;
 
     uint32_t sect[4] = {0u, 0u, 0u, 0u};
     typename std::conditional<COUNT, ClockProf, NoProf>::type prof;
@@ -640,7 +643,11 @@ __global__ void __launch_bounds__(kBlock, SRT_WAVES_PER_SIMD_MESH) mesh_trace_ke
         }
         if (lane_phase == LANE_IDLE) {
             if (deliver >= 0) { ln.former = ret; phase = LANE_DELIVER; }
-            else { samples[ln.slot] = ret; phase = MESH_IDLE; }
+            else {
+                samples[ln.slot] = ret; phase = MESH_IDLE;
+                const uint32_t tree = ln.rays_path - item_rays_base;
+                largest_tree = tree > largest_tree ? tree : largest_tree;
+            }
         }
         else if (lane_phase == LANE_WAIT) phase = MESH_WAIT;
         else if (lane_phase == LANE_RETURN) phase = MESH_RETURN;
@@ -748,7 +755,7 @@ __global__ void __launch_bounds__(kBlock, SRT_WAVES_PER_SIMD_MESH) mesh_trace_ke
                 uint32_t avail = end - next, want = (uint32_t)__popcll(idle);
                 uint32_t rank = lanes_below(idle);
                 if (phase == MESH_IDLE && rank < avail) {
-                    if (item_start(ln, ra, next + rank, unit)) { tr.d = ln.qd; tr.cur = TRAV_NEW; phase = MESH_CLOSEST; }
+                    if (item_start(ln, ra, next + rank, unit)) { tr.d = ln.qd; tr.cur = TRAV_NEW; phase = MESH_CLOSEST; item_rays_base = ln.rays_path; }
                 }
                 next += want < avail ? want : avail;
                 idle = __ballot(phase == MESH_IDLE);
@@ -792,10 +799,15 @@ __global__ void __launch_bounds__(kBlock, SRT_WAVES_PER_SIMD_MESH) mesh_trace_ke
     }
 #endif
     unsigned long long v0 = wave_sum(ln.rays_path), v1 = wave_sum(ln.rays_shadow), v2 = wave_sum(ln.hit_nodes);
+    for (int off = 32; off > 0; off >>= 1) {
+        const uint32_t other = (uint32_t)__shfl_xor((int)largest_tree, off, 64);
+        largest_tree = other > largest_tree ? other : largest_tree;
+    }
     if (lane == 0u) {
         atomicAdd(&stats[0], v0);
         atomicAdd(&stats[1], v1);
         atomicAdd(&stats[2], v2);
+        if (largest_tree > 1u) atomicMax(&stats[kStatsLargestTree], (unsigned long long)largest_tree);
     }
     if constexpr (COUNT) {
         for (int i = 0; i < PROF_SLOTS; i++) {

@@ -36,7 +36,8 @@ struct WavefrontPool { void* mem = nullptr; size_t bytes = 0; double nodes_per_i
 enum : uint32_t { WAVEFRONT_LEVELS = 16, WAVEFRONT_LIGHTS = 4, WAVEFRONT_MAX_CHUNKS = 2048, WAVEFRONT_CONTROL_BYTES = 1024, WAVEFRONT_MAX_WALK_BLOCKS = 4096 };
 size_t wavefront_header_bytes();
 size_t wavefront_far_stack_bytes();
-enum { kStatsUnaskedWord = 48, kStatsWavefrontNodes = 49, kStatsWavefrontItems = 50, kStatsWavefrontGivenUp = 51 };
+enum { kStatsUnaskedWord = 48, kStatsWavefrontNodes = 49, kStatsWavefrontItems = 50, kStatsWavefrontGivenUp = 51,
+       kStatsLargestTree = 52 };   // 52: the largest ray tree (GetRayColor calls) a lane of mesh_trace_kernel finished (a maximum, not a sum)
 bool wavefront_serves(const SceneView& sc, const RenderArgs& ra, bool exact);
 size_t wavefront_node_bytes();                                              // pool bytes per node record
 uint32_t wavefront_capacity(size_t pool_bytes);                             // nodes a pool of that size holds (0: too small to use)

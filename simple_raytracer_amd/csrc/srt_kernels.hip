@@ -156,7 +156,9 @@ __device__ __forceinline__ uint32_t open_children(const Lane& ln, int phase, con
 }
 
 // Helpers whose giver waits for their subtree hand the colour over.
-__device__ __forceinline__ void rendezvous(Lane& ln, int& phase, TreeFork& fork, int32_t& deliver, uint32_t lane)
+// tree_base (optional): ln.rays_path - *tree_base is the size of the tree (or subtree) the lane is on; a giver's tree grows
+// by the subtree it gets back.
+__device__ __forceinline__ void rendezvous(Lane& ln, int& phase, TreeFork& fork, int32_t& deliver, uint32_t lane, uint32_t* tree_base = nullptr)
 {
     if (__ballot(phase == LANE_DELIVER) == 0ull) return;
     const int g = phase == LANE_DELIVER ? (deliver & 63) : (int)lane;
@@ -170,6 +172,10 @@ __device__ __forceinline__ void rendezvous(Lane& ln, int& phase, TreeFork& fork,
         const float x = bitsf((uint32_t)__builtin_amdgcn_readlane((int)fbits(ln.former.x), h));
         const float y = bitsf((uint32_t)__builtin_amdgcn_readlane((int)fbits(ln.former.y), h));
         const float z = bitsf((uint32_t)__builtin_amdgcn_readlane((int)fbits(ln.former.z), h));
+        if (tree_base != nullptr) {
+            const uint32_t grown = (uint32_t)__builtin_amdgcn_readlane((int)(ln.rays_path - *tree_base), h);
+            if (lane == to) *tree_base -= grown;
+        }
         if (lane == to) {
             ln.former = mk3(x, y, z);
             ln.key.node = ln.key.node * 4u + fork.wait + 1u;
@@ -689,9 +695,9 @@ __global__ void __launch_bounds__(kBlock, SRT_WAVES_PER_SIMD_MESH) mesh_trace_ke
                 if (phase != MESH_WAIT) open = open_children(ln, phase, frames, sc) & ~fork.given;
                 sharing = true;
             }
-            rendezvous(ln, phase, fork, deliver, lane);
+            rendezvous(ln, phase, fork, deliver, lane, &item_rays_base);
             if (share_open_children(ln, phase, frames, fork, open, deliver, my_pair, ra, lane, handed)) {
-                tr.d = ln.qd; tr.cur = TRAV_NEW; phase = MESH_CLOSEST;
+                tr.d = ln.qd; tr.cur = TRAV_NEW; phase = MESH_CLOSEST; item_rays_base = ln.rays_path;
             }
         }
         const bool walking = (phase == MESH_CLOSEST || phase == MESH_SHADOW) && tr.cur != TRAV_NONE;

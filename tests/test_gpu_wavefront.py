@@ -131,6 +131,25 @@ def test_given_up_chunks_never_read_what_they_could_not_write(gpu_renderer_facto
         assert st[k] == ost[k], k
 
 
+def test_one_deep_tree_is_enough(gpu_renderer_factory, oracle):
+    """Two small glossy spheres beside a mesh: few rays per sample on average, but every sample that meets a sphere grows a
+    tree of hundreds of calls, which one lane of the one-kernel tracer would walk node after node.  The probe sample reports
+    the largest tree it saw, and that alone sends the scene to the level-by-level tracer."""
+    spec = helpers.mesh_spec(n=8, with_spheres=False)
+    spec.materials.append(((0.9, 0.8, 0.7), 0.5, 1.0, (0, 0, 0)))
+    spec.spheres = [((-2.2, 0.4, -5.0), 0.35, len(spec.materials) - 1), ((2.4, -0.6, -5.5), 0.3, len(spec.materials) - 1)]
+    w, h = 128, 72
+    ref, ost = spec.oracle_scene().render(spec.oracle_camera(w, h), w, h, samples=3, max_depth=8, seed=3, world_kind=oracle.WORLD_SURFACELIST)
+    assert ost["rays_path"] < 5 * 3 * w * h                      # the average would not have done it
+    r = gpu_renderer_factory()
+    r.set_scene(*spec.host(w, h), world_kind=srt.WORLD_SURFACELIST)
+    img = r.render(w, h, samples=3, max_depth=8, seed=3)
+    st = r.stats()
+    r.close()
+    assert helpers.max_lsb_diff(img, ref) == (0, 0) and st["rays_path"] == ost["rays_path"]
+    assert st["wavefront_items"] >= 2 * w * h
+
+
 def test_asynchronous_first_render_switches_after_its_probe_sample(gpu_renderer_factory, oracle):
     """srt_render_async of a new scene queues one sample per pixel; srt_poll (or srt_wait) finds it done, reads the ray count
     and queues the other samples for the tracer the count calls for.  The frame is the blocking render's."""

@@ -176,6 +176,24 @@ def test_asynchronous_first_render_switches_after_its_probe_sample(gpu_renderer_
         assert st["wavefront_items"] >= 2 * w * h and st["rays_path"] == ost["rays_path"]       # samples 1 and 2 of every pixel
 
 
+def test_contexts_with_several_devices_use_it_on_every_device(oracle):
+    """A context over the one GPU named twice: the first frame measures the scene on both replicas, the second is traced
+    level by level on both (each replica has its own pool); same picture as the oracle's."""
+    spec = deep_tree_spec()
+    w, h = 128, 72
+    ref, ost = spec.oracle_scene().render(spec.oracle_camera(w, h), w, h, samples=2, max_depth=8, seed=9, world_kind=oracle.WORLD_SURFACELIST)
+    r = srt.Renderer(devices=[0, 0], gather=srt.GATHER_PEER_COPY)
+    r.set_scene(*spec.host(w, h), world_kind=srt.WORLD_SURFACELIST)
+    first = r.render(w, h, samples=2, max_depth=8, seed=9)
+    assert r.stats()["wavefront_items"] == 0
+    second = r.render(w, h, samples=2, max_depth=8, seed=9)
+    st = r.stats()
+    per_device = [r.device_stats(i)["wavefront_items"] for i in range(2)]
+    r.close()
+    assert np.array_equal(first, ref) and np.array_equal(second, ref)
+    assert all(n > 0 for n in per_device) and st["wavefront_items"] == sum(per_device) and st["rays_path"] == ost["rays_path"]
+
+
 def test_tiles_passes_and_padding_pixels(gpu_renderer_factory, forced, monkeypatch):
     """Tile layout with edge tiles (padding pixels are dead nodes), several sample passes (a small sample buffer) and a rank
     that owns a part of the tiles: the same pixels as the one-kernel tracer."""

@@ -625,7 +625,10 @@ hipError_t launch_wavefront_chunk(const SceneView& sc, const RenderArgs& ra, boo
         if (std::getenv("SRT_DEBUG_LAUNCH")) std::fprintf(stderr, "srt: wavefront walkers: %u resident blocks\n", walk_blocks);
     }
     static const int grid_knob = std::getenv("SRT_WF_GRID") ? std::atoi(std::getenv("SRT_WF_GRID")) : kGridBlocks;
+    static const int hit_knob = std::getenv("SRT_WF_HIT_GRID") ? std::atoi(std::getenv("SRT_WF_HIT_GRID")) : 0;       // experiments
+    static const int shade_knob = std::getenv("SRT_WF_SHADE_GRID") ? std::atoi(std::getenv("SRT_WF_SHADE_GRID")) : 0;
     const dim3 block(kBlock), grid(grid_knob > 0 ? grid_knob : kGridBlocks), walkers(walk_blocks);
+    const dim3 hit_grid(hit_knob > 0 ? hit_knob : (int)grid.x), shade_grid(shade_knob > 0 ? shade_knob : (int)grid.x);
     const uint32_t n_items = item1 - item0;
     const uint32_t gen_blocks = (n_items + kBlock - 1) / kBlock;
     hipLaunchKernelGGL(wf_generate, dim3(gen_blocks < (uint32_t)kGridBlocks ? gen_blocks : (uint32_t)kGridBlocks), block, 0, stream, ra, pool, item0, item1);
@@ -633,10 +636,10 @@ hipError_t launch_wavefront_chunk(const SceneView& sc, const RenderArgs& ra, boo
     for (uint32_t l = 0; l < levels; l++) {
         if (counted) hipLaunchKernelGGL((wf_walk<false, true>), walkers, block, 0, stream, sc, pool, l, rounds, steps, refill);
         else hipLaunchKernelGGL((wf_walk<false, false>), walkers, block, 0, stream, sc, pool, l, rounds, steps, refill);
-        hipLaunchKernelGGL(wf_hit, grid, block, 0, stream, sc, ra, pool, l);
+        hipLaunchKernelGGL(wf_hit, hit_grid, block, 0, stream, sc, ra, pool, l);
         if (counted) hipLaunchKernelGGL((wf_walk<true, true>), walkers, block, 0, stream, sc, pool, l, rounds, steps, refill);
         else hipLaunchKernelGGL((wf_walk<true, false>), walkers, block, 0, stream, sc, pool, l, rounds, steps, refill);
-        hipLaunchKernelGGL(wf_shade, grid, block, 0, stream, sc, ra, pool, l);
+        hipLaunchKernelGGL(wf_shade, shade_grid, block, 0, stream, sc, ra, pool, l);
     }
     for (uint32_t l = levels; l-- > 0u;) {
         if (l + 1u >= levels) continue;   // the nodes of the deepest level have no children

@@ -9,7 +9,7 @@
 //   generate                 the primary rays of the chunk's items: the nodes of level 0
 //   per level l:
 //     walk<closest>          the closest-hit query of every node of the level (persistent wavefronts, lanes refilled as
-//                            their traversals end; nothing but traversal, so few registers and no spills)
+//                            their traversals end; nothing but traversal, so few registers: 8 wavefronts per SIMD)
 //     hit                    misses get their value (the sky); hits their record, the depth heuristic and one shadow
 //                            query per light whose ray can matter (lane_on_closest, lane_shadow_matters)
 //     walk<shadow>           those queries

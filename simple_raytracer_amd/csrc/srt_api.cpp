@@ -257,8 +257,12 @@ int collect_stats(srt_ctx* c)
         p.shadow_unasked = s[48];
         if (d.walk_tune == WALK_TUNE_CALIBRATE && s[13] >= kWalkTuneEnoughTicks && s[15] >= kWalkTuneEnoughTicks)
             d.walk_tune = walk_tune_prefers_short((double)s[12], (double)s[13], (double)s[14], (double)s[15]) ? WALK_TUNE_SHORT : WALK_TUNE_LONG;
-        // nodes per work item of the level-by-level tracer's chunks: the next launches size their chunks by it
-        if (s[kStatsWavefrontItems] != 0ull) d.wavefront.nodes_per_item = (double)s[kStatsWavefrontNodes] / (double)s[kStatsWavefrontItems];
+        // pool entries per work item of the level-by-level tracer's chunks (node records, or one level's shadow queries
+        // where those are more): the next launches size their chunks by it
+        if (s[kStatsWavefrontItems] != 0ull) {
+            const unsigned long long entries = s[kStatsWavefrontNodes] > s[kStatsWavefrontQueue] ? s[kStatsWavefrontNodes] : s[kStatsWavefrontQueue];
+            d.wavefront.nodes_per_item = (double)entries / (double)s[kStatsWavefrontItems];
+        }
         if (s[kStatsWavefrontGivenUp] != 0ull) d.wavefront.nodes_per_item = 2.0 * (d.wavefront.nodes_per_item > 0.0 ? d.wavefront.nodes_per_item : 24.0);
         p.wavefront_items = s[kStatsWavefrontItems]; p.wavefront_nodes = s[kStatsWavefrontNodes]; p.wavefront_given_up = s[kStatsWavefrontGivenUp];
         if (d.items_since_collect != 0) d.rays_per_item = (double)s[0] / (double)d.items_since_collect;

@@ -554,6 +554,10 @@ __global__ void __launch_bounds__(kBlock) wf_finish(WfPool pool, f3* __restrict_
         unsigned long long nodes = 0ull;
         for (uint32_t l = 0; l <= WAVEFRONT_LEVELS; l++) nodes += ctrl->level_count[l];
         atomicAdd(&stats[kStatsWavefrontNodes], nodes);
+        // the shadow queries of a level share the pool's capacity too: the largest queue of the chunk
+        uint32_t queue = 0u;
+        for (uint32_t l = 0; l < WAVEFRONT_LEVELS; l++) queue = ctrl->shadow_count[l] > queue ? ctrl->shadow_count[l] : queue;
+        atomicAdd(&stats[kStatsWavefrontQueue], (unsigned long long)queue);
         atomicAdd(&stats[kStatsWavefrontItems], (unsigned long long)n);
     }
 }

@@ -194,6 +194,32 @@ def test_contexts_with_several_devices_use_it_on_every_device(oracle):
     assert all(n > 0 for n in per_device) and st["wavefront_items"] == sum(per_device) and st["rays_path"] == ost["rays_path"]
 
 
+def test_four_lights_and_shallow_trees_size_their_chunks_by_the_shadow_queue(gpu_renderer_factory, oracle, forced, monkeypatch):
+    """With four lights all around and depth 2 a level has more shadow queries than the chunk has node records; the queue
+    shares the pool's capacity, so the chunks are sized by it once it has been seen: a render may give chunks up (they are
+    traced by the stand-by kernel), but renders after a clean one stay clean instead of alternating.  32 MiB hold about
+    160,000 entries for 294,912 samples; the camera looks down at the floor, so every sample asks about every light."""
+    monkeypatch.setenv("SRT_WAVEFRONT_POOL_MB", "32")
+    spec = helpers.mesh_spec(n=8)
+    spec.camera = ((0, 0, 0), (0.0, 1.9, -5.0), 30)
+    spec.lights = [((4.0, -3.0, 1.0), 5.0, None), ((-3.0, -2.0, -2.0), 2.0, (1.2, 0.4, 0.4)),
+                   ((0.0, -4.0, 2.0), 3.0, None), ((-4.0, -3.0, 3.0), 2.0, (0.4, 0.4, 1.2))]
+    w, h = 512, 288
+    ref, ost = spec.oracle_scene().render(spec.oracle_camera(w, h), w, h, samples=2, max_depth=2, seed=6, world_kind=oracle.WORLD_SURFACELIST)
+    assert ost["rays_shadow"] > 2 * ost["rays_path"]          # the case: more queries than nodes
+    r = gpu_renderer_factory()
+    r.set_scene(*spec.host(w, h), world_kind=srt.WORLD_SURFACELIST)
+    given_up = []
+    for _ in range(5):
+        img = r.render(w, h, samples=2, max_depth=2, seed=6)
+        st = r.stats()
+        assert helpers.max_lsb_diff(img, ref) == (0, 0) and st["rays_path"] == ost["rays_path"] and st["rays_shadow"] == ost["rays_shadow"]
+        given_up.append(st["wavefront_given_up"])
+    r.close()
+    clean = given_up.index(0)                                  # some render is clean ...
+    assert all(g == 0 for g in given_up[clean:]), given_up     # ... and so is every render after it
+
+
 def test_tiles_passes_and_padding_pixels(gpu_renderer_factory, forced, monkeypatch):
     """Tile layout with edge tiles (padding pixels are dead nodes), several sample passes (a small sample buffer) and a rank
     that owns a part of the tiles: the same pixels as the one-kernel tracer."""

@@ -381,7 +381,10 @@ def main():
                        "scene_commit_s": round(commit_s, 3), "bvh_nodes": cst["bvh_nodes"], "surfaces": cst["n_prims"],
                        "walk_tune": cst["walk_tune"], "tracer": "level-by-level" if level_by_level else "one kernel",
                        "node_records_per_ray": round(timed_stats.get("wavefront_nodes", 0) / max(1, timed_stats.get("rays_path", 1)), 3) if level_by_level else None,
-                       "chunks_given_up": int(timed_stats.get("wavefront_given_up", 0))},
+                       "chunks_given_up": int(timed_stats.get("wavefront_given_up", 0)),
+                       # path rays (counted in path_rays_per_step like every GetRayColor call) whose closest-hit query was the query of
+                       # the call before them -- the metalness and the reflectivity pass follow one ray -- and was not walked twice
+                       "path_rays_sharing_a_query": int(timed_stats.get("wavefront_twins", 0))},
             "rays_per_step": total_rays / args.steps, "shadow_rays_per_step": total_shadow / args.steps,
             "traversals_per_sec_M": round((total_rays + total_shadow) / elapsed / 1e6, 2),
             "roofline": roofline,

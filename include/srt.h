@@ -183,8 +183,13 @@ typedef struct {
        GetRayColor and level) instead of one tree per lane.  Work items (samples) traced that way in the last render, the
        node records they took (reservation holes included), and the chunks of items whose trees outgrew the pool and
        were traced by the one-kernel tracer after all (same colours, same counts).  The items include the padding pixels
-       of edge tiles. */
-    uint64_t wavefront_items, wavefront_nodes, wavefront_given_up;
+       of edge tiles.
+       wavefront_twins: GetRayColor calls of the last render whose world.hit was not computed again because the call
+       before it asked the same question: the metalness pass and the reflectivity pass of a surface with 0 < metalness
+       < 1 are both given CustomRay(record.point, reflectedDirection) (RaytracingOperations.cs:160,163), and world.hit
+       is a function of the ray.  They are part of rays_path like every other call; srt_render_counted reports them
+       too but walks the tree for them all the same (its test counts are those of a tracer that asks every question). */
+    uint64_t wavefront_items, wavefront_nodes, wavefront_given_up, wavefront_twins;
 } srt_stats;
 
 typedef struct srt_ctx srt_ctx;

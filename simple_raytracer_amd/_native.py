@@ -59,7 +59,7 @@ class Stats(C.Structure):
                 ("trace_sections", C.c_uint64), ("trace_lanes", C.c_uint64), ("light_sections", C.c_uint64), ("light_lanes", C.c_uint64),
                 ("section_cycles", C.c_uint64 * 16), ("section_lane_cycles", C.c_uint64 * 16),
                 ("shadow_unasked", C.c_uint64), ("gather_ms", C.c_double), ("assemble_ms", C.c_double),
-                ("wavefront_items", C.c_uint64), ("wavefront_nodes", C.c_uint64), ("wavefront_given_up", C.c_uint64)]
+                ("wavefront_items", C.c_uint64), ("wavefront_nodes", C.c_uint64), ("wavefront_given_up", C.c_uint64), ("wavefront_twins", C.c_uint64)]
 
 
 # every symbol include/srt.h declares: (name, restype, argtypes)

@@ -222,7 +222,7 @@ void zero_counts(srt_stats& s)
     s.trace_sections = s.trace_lanes = s.light_sections = s.light_lanes = 0;
     for (int i = 0; i < 16; i++) s.section_cycles[i] = s.section_lane_cycles[i] = 0;
     s.shadow_unasked = 0;
-    s.wavefront_items = s.wavefront_nodes = s.wavefront_given_up = 0;
+    s.wavefront_items = s.wavefront_nodes = s.wavefront_given_up = s.wavefront_twins = 0;
     s.kernel_ms = 0.0;
 }
 
@@ -264,7 +264,7 @@ int collect_stats(srt_ctx* c)
             d.wavefront.nodes_per_item = (double)entries / (double)s[kStatsWavefrontItems];
         }
         if (s[kStatsWavefrontGivenUp] != 0ull) d.wavefront.nodes_per_item = 2.0 * (d.wavefront.nodes_per_item > 0.0 ? d.wavefront.nodes_per_item : 24.0);
-        p.wavefront_items = s[kStatsWavefrontItems]; p.wavefront_nodes = s[kStatsWavefrontNodes]; p.wavefront_given_up = s[kStatsWavefrontGivenUp];
+        p.wavefront_items = s[kStatsWavefrontItems]; p.wavefront_nodes = s[kStatsWavefrontNodes]; p.wavefront_given_up = s[kStatsWavefrontGivenUp]; p.wavefront_twins = s[kStatsWavefrontTwins];
         if (d.items_since_collect != 0) d.rays_per_item = (double)s[0] / (double)d.items_since_collect;
         d.items_since_collect = 0;
         if (s[kStatsLargestTree] > d.largest_tree) d.largest_tree = s[kStatsLargestTree];
@@ -290,7 +290,7 @@ int collect_stats(srt_ctx* c)
         t.trace_sections += p.trace_sections; t.trace_lanes += p.trace_lanes; t.light_sections += p.light_sections; t.light_lanes += p.light_lanes;
         for (int i = 0; i < 16; i++) { t.section_cycles[i] += p.section_cycles[i]; t.section_lane_cycles[i] += p.section_lane_cycles[i]; }
         t.shadow_unasked += p.shadow_unasked;
-        t.wavefront_items += p.wavefront_items; t.wavefront_nodes += p.wavefront_nodes; t.wavefront_given_up += p.wavefront_given_up;
+        t.wavefront_items += p.wavefront_items; t.wavefront_nodes += p.wavefront_nodes; t.wavefront_given_up += p.wavefront_given_up; t.wavefront_twins += p.wavefront_twins;
         if (p.kernel_ms > t.kernel_ms) t.kernel_ms = p.kernel_ms;
     }
     c->stats.walk_tune = (uint32_t)c->dev[0].walk_tune;

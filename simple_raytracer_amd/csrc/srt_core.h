@@ -481,7 +481,15 @@ struct LaneStack {
     SRT_HD uint32_t pop()
     {
         sp--;
-        return (NEAR >= STACK_DEPTH || sp < NEAR) ? base[sp * STRIDE] : far[(sp - NEAR) * STRIDE];
+        if (NEAR >= STACK_DEPTH) return base[sp * STRIDE];
+        // the LDS read is unconditional and the far read a branch few lanes take: a select between the two addresses
+        // would be one flat load, which goes through the texture-address unit for every lane
+        uint32_t v = base[(sp < NEAR ? sp : NEAR - 1) * STRIDE];
+#if defined(__HIP_DEVICE_COMPILE__)
+        asm volatile("" : "+v"(v));     // (keeps the compiler from merging the two reads into that select all the same)
+#endif
+        if (sp >= NEAR) v = far[(sp - NEAR) * STRIDE];
+        return v;
     }
 };
 

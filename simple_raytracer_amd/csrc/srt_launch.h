@@ -11,7 +11,7 @@ namespace srt {
 // One pass of the trace kernel over samples [ra.sample_first, ra.sample_first + ra.sample_count) of this
 // rank's pixels.  d_samples: 3 floats per (sample, pixel), sample-major, ra.sample_count * ra.n_work entries.
 // d_stats: 56 x uint64 the kernel adds to: rays_path, rays_shadow, hit_nodes, box_tests, sphere_tests,
-// tri_tests, rect_tests, section counts, alarm; [16, 32) cycles per part, [32, 48) the same weighted by active lanes, 48 shadow queries answered without a traversal, 49-51 the level-by-level tracer's node records, work items and given-up chunks, 52 the largest ray tree a lane of mesh_trace_kernel finished (a maximum), 53 the level-by-level tracer's largest shadow queue of a chunk, summed over its chunks.  d_work_counter: one uint32, reset by the launcher on `stream`.
+// tri_tests, rect_tests, section counts, alarm; [16, 32) cycles per part, [32, 48) the same weighted by active lanes, 48 shadow queries answered without a traversal, 49-51 the level-by-level tracer's node records, work items and given-up chunks, 52 the largest ray tree a lane of mesh_trace_kernel finished (a maximum), 53 the level-by-level tracer's largest shadow queue of a chunk, summed over its chunks, 54 its closest-hit queries that took over the answer of the same ray's query one node earlier.  d_work_counter: one uint32, reset by the launcher on `stream`.
 // d_timeline: trace_timeline_bytes() of device memory; only -DSRT_TIMELINE builds write to it (per-wavefront clock records).
 // d_frame_slab: slab_bytes of device memory, where the wavefronts keep the frames of pending ray-tree nodes that do not
 // fit their LDS: trace_frame_slab_block_bytes() per block of the persistent grid, trace_frame_slab_bytes() for the largest
@@ -37,7 +37,7 @@ enum : uint32_t { WAVEFRONT_LEVELS = 16, WAVEFRONT_LIGHTS = 4, WAVEFRONT_MAX_CHU
 size_t wavefront_header_bytes();
 size_t wavefront_far_stack_bytes();
 enum { kStatsUnaskedWord = 48, kStatsWavefrontNodes = 49, kStatsWavefrontItems = 50, kStatsWavefrontGivenUp = 51,
-       kStatsLargestTree = 52, kStatsWavefrontQueue = 53 };   // 52: the largest ray tree (GetRayColor calls) a lane of mesh_trace_kernel finished (a maximum, not a sum)
+       kStatsLargestTree = 52, kStatsWavefrontQueue = 53, kStatsWavefrontTwins = 54 };   // 52: the largest ray tree (GetRayColor calls) a lane of mesh_trace_kernel finished (a maximum, not a sum)
 bool wavefront_serves(const SceneView& sc, const RenderArgs& ra, bool exact);
 size_t wavefront_node_bytes();                                              // pool bytes per node record
 uint32_t wavefront_capacity(size_t pool_bytes);                             // nodes a pool of that size holds (0: too small to use)

@@ -69,11 +69,12 @@ struct WfControl {
     uint32_t overflow;                        // non-zero: the chunk is given up
     uint32_t pad_;
     unsigned long long tally[8];              // rays_path, rays_shadow, hit_nodes, box, sphere, tri, rect tests, unasked
+    unsigned long long twins;                 // closest-hit queries answered by the query of the node before them (see wf_shade)
 };
 static_assert(sizeof(WfControl) <= WAVEFRONT_CONTROL_BYTES, "the control block outgrew its reservation");
 
 // The pool: one array of 16-byte words per field, `capacity` entries each.
-//   ray0 (o.xyz d.x)  ray1 (d.y d.z depth -)  id (slot pixel sample node)  hit (t prim u v)
+//   ray0 (o.xyz d.x)  ray1 (d.y d.z depth twin)  id (slot pixel sample node)  hit (t prim u v)
 //   pn0 (P.xyz material | depth after the heuristic << 24)  pn1 (N.xyz asked-lights mask)
 //   sh0 / sh1 (t prim) of the shadow queries of lights 0,1 / 2,3
 //   fr0 (emission.xyz w_refl)  fr1 (lightColor.xyz -)  val (value.xyz, WF_NONE | WF_LIT | index of the first child)
@@ -247,7 +248,8 @@ __global__ void __launch_bounds__(kBlock, SRT_WAVEFRONT_WALK_WAVES) wf_walk(Scen
     for (;;) {
         unsigned long long idle = __ballot(q == WF_NONE);
         if (!dry && (int)__popcll(idle) >= refill) {
-            while (idle != 0ull) {
+            // (until fewer than `refill` lanes are idle: entries can be holes, and a pass of this loop costs the same for one lane as for 64)
+            while ((int)__popcll(idle) >= refill) {
                 if (next >= end) {
                     uint32_t b = 0u;
                     if (lane == 0u) b = atomicAdd(cursor, draw);
@@ -265,7 +267,9 @@ __global__ void __launch_bounds__(kBlock, SRT_WAVEFRONT_WALK_WAVES) wf_walk(Scen
                     if (SHADOW) { r0 = ld(&pool.sq0[mine]); r1 = ld(&pool.sq1[mine]); tag0 = fbits(r1.z); tag1 = fbits(r1.w); }
                     else { r0 = ld(&pool.ray0[base + mine]); r1 = ld(&pool.ray1[base + mine]); }
                     // left over from a reservation / a dead node; a query whose node or light is out of range cannot be one of ours
-                    const bool hole = SHADOW ? (tag1 >= WAVEFRONT_LIGHTS || tag0 >= pool.capacity) : fbits(r1.z) == 0u;
+                    // (a twin -- same ray as the node before it -- is answered by that node's query; counting builds walk it all the same, so that
+                    // their test counts stay those of the one-kernel tracer)
+                    const bool hole = SHADOW ? (tag1 >= WAVEFRONT_LIGHTS || tag0 >= pool.capacity) : (fbits(r1.z) == 0u || (!COUNT && fbits(r1.w) != 0u));
                     if (!hole) {
                         q = mine;
                         o = mk3(r0.x, r0.y, r0.z);
@@ -311,7 +315,8 @@ __global__ void __launch_bounds__(kBlock, SRT_WAVEFRONT_WALK_WAVES) wf_walk(Scen
     }
 }
 
-__device__ __forceinline__ void load_node(const WfPool& pool, uint32_t g, const RenderArgs& ra, Lane& ln)
+// Returns whether the node is a twin: its ray is the ray of node g - 1.
+__device__ __forceinline__ bool load_node(const WfPool& pool, uint32_t g, const RenderArgs& ra, Lane& ln)
 {
     const q4 a = ld(&pool.ray0[g]), b = ld(&pool.ray1[g]), c = ld(&pool.id[g]);
     ln.qo = mk3(a.x, a.y, a.z);
@@ -321,6 +326,7 @@ __device__ __forceinline__ void load_node(const WfPool& pool, uint32_t g, const 
     ln.slot = fbits(c.x);
     ln.key.seed = ra.seed; ln.key.pixel = fbits(c.y); ln.key.sample = fbits(c.z); ln.key.node = fbits(c.w);
     ln.level = 0;
+    return fbits(b.w) != 0u;
 }
 
 // Closest-hit queries that are answered (lane_on_closest), and the shadow queries of the hits.
@@ -340,7 +346,7 @@ __global__ void __launch_bounds__(kBlock, SRT_WF_HIT_WAVES) wf_hit(SceneView sc,
     // where the next level starts (the shade kernel of this level allocates there)
     if (blockIdx.x == 0u && threadIdx.x == 0u) ctrl->level_base[level + 1u] = base + n;
     const uint32_t lane = threadIdx.x & 63u;
-    uint32_t rays_path = 0u, hit_nodes = 0u, unasked = 0u;
+    uint32_t rays_path = 0u, hit_nodes = 0u, unasked = 0u, twins = 0u;
     WaveRange queue;
     const uint32_t grab = grab_size(n, sc.n_lights);
     auto hole = [&](uint32_t j) { st(&pool.sq1[j], mkq(0.0f, 0.0f, 0.0f, bitsf(WF_NONE))); };
@@ -351,8 +357,9 @@ __global__ void __launch_bounds__(kBlock, SRT_WF_HIT_WAVES) wf_hit(SceneView sc,
         ln.rays_path = ln.rays_shadow = ln.hit_nodes = 0u;
         int p = LANE_IDLE;
         if (valid) {
-            load_node(pool, g, ra, ln);
-            const q4 hw = ld(&pool.hit[g]);
+            const bool twin = load_node(pool, g, ra, ln);
+            twins += twin ? 1u : 0u;
+            const q4 hw = ld(&pool.hit[twin ? g - 1u : g]);   // a twin is never the first child of its parent
             Hit h;
             h.t = hw.x; h.prim = fbits(hw.y); h.u = hw.z; h.v = hw.w; h.order = 0u;
             Frame unused;
@@ -389,11 +396,12 @@ __global__ void __launch_bounds__(kBlock, SRT_WF_HIT_WAVES) wf_hit(SceneView sc,
         }
     }
     wave_release(queue, pool.capacity, hole);
-    const unsigned long long v0 = wave_sum(rays_path), v2 = wave_sum(hit_nodes), v7 = wave_sum(unasked);
+    const unsigned long long v0 = wave_sum(rays_path), v2 = wave_sum(hit_nodes), v7 = wave_sum(unasked), vt = wave_sum(twins);
     if (lane == 0u && (v0 | v2 | v7) != 0ull) {
         atomicAdd(&ctrl->tally[0], v0);
         atomicAdd(&ctrl->tally[2], v2);
         atomicAdd(&ctrl->tally[7], v7);
+        if (vt != 0ull) atomicAdd(&ctrl->twins, vt);
     }
 }
 
@@ -483,11 +491,15 @@ __global__ void __launch_bounds__(kBlock, SRT_WF_SHADE_WAVES) wf_shade(SceneView
         st(&pool.ray1[at], mkq(ln.qd.y, ln.qd.z, depth_word, 0.0f));
         st(&pool.id[at], mkq(0.0f, bitsf(ln.key.pixel), bitsf(ln.key.sample), bitsf(parent * 4u + 1u)));
         at++;
-        // children 1 (metal) and 2 (reflection) share the reflected direction
+        // children 1 (metal) and 2 (reflection) are traced along the same ray (RaytracingOperations.cs:160,163: both calls get
+        // CustomRay(record.point, reflectedDirection)), so world.hit answers both alike: where a node has both, the second is
+        // marked as the twin of the first and takes over its answer instead of walking the tree again.  Everything after the
+        // query differs between them (the random numbers are keyed by the node), so both stay nodes of their own.
         for (uint32_t k = 1u; k < 3u; k++) {
             if (k == 1u ? metal == 0.0f : metal == 1.0f) continue;
+            const bool twin = k == 2u && metal != 0.0f;
             st(&pool.ray0[at], mkq(f.point.x, f.point.y, f.point.z, f.refl.x));
-            st(&pool.ray1[at], mkq(f.refl.y, f.refl.z, depth_word, 0.0f));
+            st(&pool.ray1[at], mkq(f.refl.y, f.refl.z, depth_word, bitsf(twin ? 1u : 0u)));
             st(&pool.id[at], mkq(0.0f, bitsf(ln.key.pixel), bitsf(ln.key.sample), bitsf(parent * 4u + k + 1u)));
             at++;
         }
@@ -558,6 +570,7 @@ __global__ void __launch_bounds__(kBlock) wf_finish(WfPool pool, f3* __restrict_
         uint32_t queue = 0u;
         for (uint32_t l = 0; l < WAVEFRONT_LEVELS; l++) queue = ctrl->shadow_count[l] > queue ? ctrl->shadow_count[l] : queue;
         atomicAdd(&stats[kStatsWavefrontQueue], (unsigned long long)queue);
+        atomicAdd(&stats[kStatsWavefrontTwins], ctrl->twins);
         atomicAdd(&stats[kStatsWavefrontItems], (unsigned long long)n);
     }
 }

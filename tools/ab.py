@@ -40,7 +40,7 @@ def child(configs, reps):
             img = r.render(W, H, samples=spp, max_depth=depth, seed=1)
             st = r.stats()
             ms.append(st["kernel_ms"])
-        out[name] = {"min": round(min(ms), 3), "med": round(float(np.median(ms)), 3), "rays": st["rays_path"], "tune": st["walk_tune"], "wf_nodes_per_ray": round(st["wavefront_nodes"] / max(st["rays_path"], 1), 3), "wf_given_up": st["wavefront_given_up"],
+        out[name] = {"min": round(min(ms), 3), "med": round(float(np.median(ms)), 3), "rays": st["rays_path"], "tune": st["walk_tune"], "wf_nodes_per_ray": round(st["wavefront_nodes"] / max(st["rays_path"], 1), 3), "wf_given_up": st["wavefront_given_up"], "wf_twins": st["wavefront_twins"],
                      "crc": int(np.bitwise_xor.reduce(img.ravel().astype(np.uint64) * np.arange(1, img.size + 1, dtype=np.uint64)) & np.uint64(0xFFFFFFFF))}
     print(json.dumps(out), flush=True)
 

@@ -58,7 +58,7 @@ constexpr int kWaves = kBlock / 64;
 constexpr uint32_t WF_NONE = 0xFFFFFFFFu;   // val.w: the node's value is final
 constexpr uint32_t WF_LIT = 0xFFFFFFFEu;    // val.w: the node was hit and waits for its shading
 constexpr uint32_t kDraw = 1024;            // queries a walking wavefront draws at a time while there are plenty
-constexpr int kGridBlocks = 256 * 3;        // grid of the per-node kernels (they stride over the level): 3 blocks per CU, what wf_shade's registers
+constexpr int kGridBlocks = 256 * 3;        // grid of wf_shade (the per-node kernels stride over the level): 3 blocks per CU, what its registers
                                             // allow (10,000-sphere frame: 1024 blocks 181.0 ms, 896 186.8, 768 177.8, 640 186.0, 512 189.7)
 
 struct WfControl {
@@ -641,11 +641,13 @@ hipError_t launch_wavefront_chunk(const SceneView& sc, const RenderArgs& ra, boo
         if (walk_blocks > WAVEFRONT_MAX_WALK_BLOCKS) walk_blocks = WAVEFRONT_MAX_WALK_BLOCKS;   // the far stacks are sized for that many
         if (std::getenv("SRT_DEBUG_LAUNCH")) std::fprintf(stderr, "srt: wavefront walkers: %u resident blocks\n", walk_blocks);
     }
-    static const int grid_knob = std::getenv("SRT_WF_GRID") ? std::atoi(std::getenv("SRT_WF_GRID")) : kGridBlocks;
-    static const int hit_knob = std::getenv("SRT_WF_HIT_GRID") ? std::atoi(std::getenv("SRT_WF_HIT_GRID")) : 0;       // experiments
-    static const int shade_knob = std::getenv("SRT_WF_SHADE_GRID") ? std::atoi(std::getenv("SRT_WF_SHADE_GRID")) : 0;
-    const dim3 block(kBlock), grid(grid_knob > 0 ? grid_knob : kGridBlocks), walkers(walk_blocks);
-    const dim3 hit_grid(hit_knob > 0 ? hit_knob : (int)grid.x), shade_grid(shade_knob > 0 ? shade_knob : (int)grid.x);
+    // Grids of the per-node kernels, in blocks per CU what their registers allow: wf_shade 3, wf_hit 4, the small ones 6
+    // (10,000-sphere frame: all on 768 blocks 147.8 ms, wf_hit on 1024 146.0, the small ones on 1536 as well 145.7).
+    static const int grid_knob = std::getenv("SRT_WF_GRID") ? std::atoi(std::getenv("SRT_WF_GRID")) : 2 * kGridBlocks;       // experiments
+    static const int hit_knob = std::getenv("SRT_WF_HIT_GRID") ? std::atoi(std::getenv("SRT_WF_HIT_GRID")) : 256 * SRT_WF_HIT_WAVES;
+    static const int shade_knob = std::getenv("SRT_WF_SHADE_GRID") ? std::atoi(std::getenv("SRT_WF_SHADE_GRID")) : kGridBlocks;
+    const dim3 block(kBlock), grid(grid_knob > 0 ? grid_knob : 2 * kGridBlocks), walkers(walk_blocks);
+    const dim3 hit_grid(hit_knob > 0 ? hit_knob : kGridBlocks), shade_grid(shade_knob > 0 ? shade_knob : kGridBlocks);
     const uint32_t n_items = item1 - item0;
     const uint32_t gen_blocks = (n_items + kBlock - 1) / kBlock;
     hipLaunchKernelGGL(wf_generate, dim3(gen_blocks < (uint32_t)kGridBlocks ? gen_blocks : (uint32_t)kGridBlocks), block, 0, stream, ra, pool, item0, item1);

@@ -262,3 +262,38 @@ def test_scenes_it_does_not_serve_keep_their_tracer(gpu_renderer_factory, forced
     r.render(64, 36, samples=1, max_depth=4, seed=1)
     assert r.stats()["wavefront_items"] >= 64 * 36
     r.close()
+
+
+def test_level_by_level_render_can_be_recorded_into_a_graph(oracle):
+    """srt_render_device of a scene that the level-by-level tracer serves, recorded by stream capture once the pool exists
+    and the scene's ray count is known (two renders outside the capture): the chunk's memsets and its few dozen kernels
+    become the graph, every replay writes the blocking render's picture, and the context works as before afterwards."""
+    import torch
+    spec = deep_tree_spec()
+    w, h = 96, 54
+    ref, ost = spec.oracle_scene().render(spec.oracle_camera(w, h), w, h, samples=2, max_depth=8, seed=9, world_kind=oracle.WORLD_SURFACELIST)
+    r = srt.Renderer(device=0)
+    r.set_scene(*spec.host(w, h), world_kind=srt.WORLD_SURFACELIST)
+    assert np.array_equal(r.render(w, h, samples=2, max_depth=8, seed=9), ref)
+    p = r.params(w, h, samples=2, max_depth=8, seed=9)
+    side = torch.cuda.Stream()
+    out = torch.zeros(w * h, dtype=torch.int32, device="cuda")
+    with torch.cuda.stream(side):
+        r.render_device(p, out.data_ptr(), w * h, side.cuda_stream)       # outside the capture: buffers of this size exist afterwards
+    side.synchronize()
+    assert r.stats()["wavefront_items"] >= 2 * w * h
+    assert np.array_equal(out.cpu().numpy().view(np.uint32).reshape(h, w), ref)
+    graph = torch.cuda.CUDAGraph()
+    out.zero_()
+    with torch.cuda.graph(graph, stream=side):
+        r.render_device(p, out.data_ptr(), w * h, side.cuda_stream)
+    assert int(out.abs().sum().item()) == 0        # recorded, not run
+    for _ in range(2):
+        out.zero_()
+        graph.replay()
+        torch.cuda.synchronize()
+        assert np.array_equal(out.cpu().numpy().view(np.uint32).reshape(h, w), ref)
+    again = r.render(w, h, samples=2, max_depth=8, seed=9)
+    st = r.stats()
+    r.close()
+    assert np.array_equal(again, ref) and st["wavefront_given_up"] == 0 and st["rays_path"] % ost["rays_path"] == 0

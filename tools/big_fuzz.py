@@ -10,6 +10,17 @@ gpu = srt.Renderer(device=0); emu = srt.Renderer(library=helpers.EMU_LIB, strict
 cases = [("glossy", helpers.glossy_spec, 640, 360, 2, 6, srt.WORLD_BVHNODE), ("default", helpers.default_spec, 960, 540, 3, 12, srt.WORLD_BVHNODE),
          ("glossy-list", helpers.glossy_spec, 480, 270, 1, 7, srt.WORLD_SURFACELIST), ("mesh", lambda: helpers.mesh_spec(n=12), 640, 360, 2, 8, srt.WORLD_SURFACELIST),
          ("mesh-bvh", lambda: helpers.mesh_spec(n=10), 480, 270, 2, 8, srt.WORLD_BVHNODE)]
+def cloud_spec():
+    """A mesh inside a cloud of half-metallic spheres: three children per hit, two of them along one ray."""
+    import numpy as np
+    spec = helpers.mesh_spec(n=8)
+    rng = np.random.default_rng(7)
+    for _ in range(200):
+        c = rng.uniform(-3, 3, 3) + np.array([0, 0, -6.0])
+        spec.materials.append((tuple(float(v) for v in rng.uniform(0.3, 1, 3)), float(rng.uniform(0, 1)), float(rng.uniform(0.5, 1)), (0, 0, 0)))
+        spec.spheres.append((tuple(float(v) for v in c), float(rng.uniform(0.1, 0.5)), len(spec.materials) - 1))
+    return spec
+cases.append(("cloud", cloud_spec, 480, 270, 3, 8, srt.WORLD_SURFACELIST))
 bad = 0
 for name, f, w, h, spp, d, kind in cases:
     sc = f().host(w, h)

@@ -475,8 +475,16 @@ int launch(srt_ctx* c, DeviceState& d, const srt_render_params* p, uint32_t* d_o
             SRT_HIP(c, hipDeviceSynchronize());      // the old pool may be in use; steady-state renders of one size never get here
             if (d.wavefront.mem) { (void)hipFree(d.wavefront.mem); d.wavefront.mem = nullptr; d.wavefront.bytes = 0; }
             if (hipMemGetInfo(&free_b, &total_b) == hipSuccess && want > free_b / 10 * 6) { want = free_b / 10 * 6; d.wavefront_full = true; }
-            if (wavefront_capacity(want) != 0u && hipMalloc(&d.wavefront.mem, want) == hipSuccess) d.wavefront.bytes = want;
-            else { d.wavefront.mem = nullptr; d.wavefront_full = true; (void)hipGetLastError(); }
+            // (an allocation that fails although the memory is said to be free is tried again at half the size: a smaller pool
+            // means more chunks, no pool means the one-kernel tracer for good)
+            while (wavefront_capacity(want) != 0u) {
+                if (hipMalloc(&d.wavefront.mem, want) == hipSuccess) { d.wavefront.bytes = want; break; }
+                (void)hipGetLastError();
+                d.wavefront.mem = nullptr;
+                d.wavefront_full = true;
+                want /= 2;
+            }
+            if (!d.wavefront.mem) d.wavefront_full = true;
             if (d.wavefront.mem && !d.wavefront.far_stacks && wavefront_far_stack_bytes() != 0 &&
                 hipMalloc(&d.wavefront.far_stacks, wavefront_far_stack_bytes()) != hipSuccess) {
                 (void)hipGetLastError();

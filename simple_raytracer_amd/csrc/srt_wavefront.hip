@@ -77,7 +77,7 @@ static_assert(sizeof(WfControl) <= WAVEFRONT_CONTROL_BYTES, "the control block o
 //   ray0 (o.xyz d.x)  ray1 (d.y d.z depth twin)  id (slot pixel sample node)  hit (t prim u v)
 //   pn0 (P.xyz material | depth after the heuristic << 24)  pn1 (N.xyz asked-lights mask)
 //   sh0 / sh1 (t prim) of the shadow queries of lights 0,1 / 2,3
-//   fr0 (emission.xyz w_refl)  fr1 (lightColor.xyz -)  val (value.xyz, WF_NONE | WF_LIT | index of the first child)
+//   fr0 (emission.xyz w_refl)  fr1 (lightColor.xyz material)  val (value.xyz, WF_NONE | WF_LIT | index of the first child)
 //   sq0 (P.xyz d.x)  sq1 (d.y d.z node light): the shadow queries of the level being worked on
 struct WfPool {
     q4 *ray0, *ray1, *id, *hit, *pn0, *pn1, *sh0, *sh1, *fr0, *fr1, *val, *sq0, *sq1;
@@ -483,7 +483,7 @@ __global__ void __launch_bounds__(kBlock, SRT_WF_SHADE_WAVES) wf_shade(SceneView
         }
         at += next_base;
         st(&pool.fr0[g], mkq(f.acc.x, f.acc.y, f.acc.z, f.w_refl));
-        st(&pool.fr1[g], mkq(f.light.x, f.light.y, f.light.z, 0.0f));
+        st(&pool.fr1[g], mkq(f.light.x, f.light.y, f.light.z, bitsf(ln.mat)));   // the material rides along: wf_combine need not read pn0
         st(&pool.val[g], mkq(0.0f, 0.0f, 0.0f, bitsf(at)));
         const float depth_word = bitsf((uint32_t)ln.depth);   // lane_shade left the children's depth here
         // child 0: the diffuse ray, which lane_shade set up as the lane's next query
@@ -528,7 +528,7 @@ __global__ void __launch_bounds__(kBlock) wf_combine(SceneView sc, RenderArgs ra
         f.acc = mk3(a.x, a.y, a.z); f.w_refl = a.w;
         f.light = mk3(b.x, b.y, b.z);
         f.point = f.refl = mk3(0.0f, 0.0f, 0.0f);
-        f.meta = fbits(ld(&pool.pn0[g]).w) & 0x00FFFFFFu;
+        f.meta = fbits(b.w) & 0x00FFFFFFu;
         LocalFrames frames{&f};
         Lane ln;
         ln.level = 1;

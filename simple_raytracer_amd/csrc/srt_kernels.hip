@@ -984,13 +984,16 @@ hipError_t launch_trace(const SceneView& sc, const RenderArgs& ra_in, bool exact
                 set_item_order(rw, 0u);   // every sample block by block: nothing there needs the deep trees spread out
                 if ((e = hipMemsetAsync(wavefront->mem, 0, (size_t)n_chunks * sizeof(uint32_t), stream)) != hipSuccess) return e;
                 uint32_t chunk_index = 0u;
-                for (uint32_t item0 = 0u; item0 < ra.n_items; item0 += per_chunk, chunk_index++) {
+                // (64-bit loop variables: a pass may have close to 2^32 items, and item0 + per_chunk must not wrap)
+                for (uint64_t at = 0u; at < ra.n_items; at += per_chunk, chunk_index++) {
+                    const uint32_t item0 = (uint32_t)at;
                     const uint32_t item1 = ra.n_items - item0 < per_chunk ? ra.n_items : item0 + per_chunk;
                     e = launch_wavefront_chunk(sc, rw, counted, d_samples, d_stats, wavefront->mem, wavefront->bytes, wavefront->far_stacks, chunk_index, item0, item1, stream);
                     if (e != hipSuccess) return e;
                 }
                 chunk_index = 0u;
-                for (uint32_t item0 = 0u; item0 < ra.n_items; item0 += per_chunk, chunk_index++) {
+                for (uint64_t at = 0u; at < ra.n_items; at += per_chunk, chunk_index++) {
+                    const uint32_t item0 = (uint32_t)at;
                     const uint32_t item1 = ra.n_items - item0 < per_chunk ? ra.n_items : item0 + per_chunk;
                     const uint32_t* given_up = wavefront_chunk_flag(wavefront->mem, chunk_index);
                     e = hipMemsetD32Async(reinterpret_cast<hipDeviceptr_t>(d_work_counter), (int)item0, 1, stream);

@@ -459,14 +459,14 @@ int launch(srt_ctx* c, DeviceState& d, const srt_render_params* p, uint32_t* d_o
     const uint64_t min_tree = min_tree_knob ? (uint64_t)std::atoll(min_tree_knob) : 32u;
     if (!fixed_ws && (d.rays_per_item >= min_rays || (min_rays > 0.0 && d.largest_tree >= min_tree)) && wavefront_serves(view, ra, exact)) {
         // The pool is sized for what the largest pass of this render is expected to need (so that it is one chunk), within
-        // SRT_WAVEFRONT_POOL_MB (default 128 GiB) and 60 % of the memory that is free; it grows when a later render needs
+        // SRT_WAVEFRONT_POOL_MB (default 192 GiB) and 60 % of the memory that is free; it grows when a later render needs
         // more and is never shrunk.  Few large chunks matter: the 10,000-sphere scene at 1080p and 16 samples takes
         // 411 ms with 4 GiB (40 chunks), 251 ms with 16 GiB (10) and 198 ms in one chunk.
         const double per_item = d.wavefront.nodes_per_item > 0.0 ? d.wavefront.nodes_per_item : 1.25 * (d.rays_per_item > 4.0 ? d.rays_per_item : 4.0);
         const uint64_t pass_items = (uint64_t)ra.n_work * (mix_buffers > 0 ? 1u : per_pass);
         const double want_nodes = 1.35 * per_item * (double)pass_items;
         size_t want = wavefront_header_bytes() + (size_t)(want_nodes * (double)wavefront_node_bytes());
-        size_t cap = (size_t)131072 << 20;
+        size_t cap = (size_t)196608 << 20;
         if (const char* mb = std::getenv("SRT_WAVEFRONT_POOL_MB")) cap = (size_t)std::atoll(mb) << 20;
         if (want > cap) want = cap;
         if (want < ((size_t)256 << 20)) want = cap < ((size_t)256 << 20) ? cap : (size_t)256 << 20;

@@ -409,7 +409,7 @@ __global__ void __launch_bounds__(kBlock, SRT_WF_HIT_WAVES) wf_hit(SceneView sc,
 #ifndef SRT_WF_SHADE_WAVES
 #define SRT_WF_SHADE_WAVES 3
 #endif
-__global__ void __launch_bounds__(kBlock, SRT_WF_SHADE_WAVES) wf_shade(SceneView sc, RenderArgs ra, WfPool pool, uint32_t level)
+__global__ void __launch_bounds__(kBlock, SRT_WF_SHADE_WAVES) wf_shade(SceneView sc, RenderArgs ra, WfPool pool, uint32_t level, uint32_t share_queries)
 {
     __shared__ float unit[UNIT_TABLE];
     fill_unit_table(unit);
@@ -497,7 +497,7 @@ __global__ void __launch_bounds__(kBlock, SRT_WF_SHADE_WAVES) wf_shade(SceneView
         // query differs between them (the random numbers are keyed by the node), so both stay nodes of their own.
         for (uint32_t k = 1u; k < 3u; k++) {
             if (k == 1u ? metal == 0.0f : metal == 1.0f) continue;
-            const bool twin = k == 2u && metal != 0.0f;
+            const bool twin = k == 2u && metal != 0.0f && share_queries != 0u;
             st(&pool.ray0[at], mkq(f.point.x, f.point.y, f.point.z, f.refl.x));
             st(&pool.ray1[at], mkq(f.refl.y, f.refl.z, depth_word, bitsf(twin ? 1u : 0u)));
             st(&pool.id[at], mkq(0.0f, bitsf(ln.key.pixel), bitsf(ln.key.sample), bitsf(parent * 4u + k + 1u)));
@@ -648,6 +648,7 @@ hipError_t launch_wavefront_chunk(const SceneView& sc, const RenderArgs& ra, boo
     static const int shade_knob = std::getenv("SRT_WF_SHADE_GRID") ? std::atoi(std::getenv("SRT_WF_SHADE_GRID")) : kGridBlocks;
     const dim3 block(kBlock), grid(grid_knob > 0 ? grid_knob : 2 * kGridBlocks), walkers(walk_blocks);
     const dim3 hit_grid(hit_knob > 0 ? hit_knob : kGridBlocks), shade_grid(shade_knob > 0 ? shade_knob : kGridBlocks);
+    const uint32_t share = std::getenv("SRT_NO_SHARED_QUERIES") ? 0u : 1u;   // measurements: every GetRayColor call walks the tree itself
     const uint32_t n_items = item1 - item0;
     const uint32_t gen_blocks = (n_items + kBlock - 1) / kBlock;
     hipLaunchKernelGGL(wf_generate, dim3(gen_blocks < (uint32_t)kGridBlocks ? gen_blocks : (uint32_t)kGridBlocks), block, 0, stream, ra, pool, item0, item1);
@@ -658,7 +659,7 @@ hipError_t launch_wavefront_chunk(const SceneView& sc, const RenderArgs& ra, boo
         hipLaunchKernelGGL(wf_hit, hit_grid, block, 0, stream, sc, ra, pool, l);
         if (counted) hipLaunchKernelGGL((wf_walk<true, true>), walkers, block, 0, stream, sc, pool, l, rounds, steps, refill);
         else hipLaunchKernelGGL((wf_walk<true, false>), walkers, block, 0, stream, sc, pool, l, rounds, steps, refill);
-        hipLaunchKernelGGL(wf_shade, shade_grid, block, 0, stream, sc, ra, pool, l);
+        hipLaunchKernelGGL(wf_shade, shade_grid, block, 0, stream, sc, ra, pool, l, share);
     }
     for (uint32_t l = levels; l-- > 0u;) {
         if (l + 1u >= levels) continue;   // the nodes of the deepest level have no children

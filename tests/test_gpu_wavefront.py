@@ -297,3 +297,22 @@ def test_level_by_level_render_can_be_recorded_into_a_graph(oracle):
     st = r.stats()
     r.close()
     assert np.array_equal(again, ref) and st["wavefront_given_up"] == 0 and st["rays_path"] % ost["rays_path"] == 0
+
+
+def test_shared_queries_can_be_turned_off(gpu_renderer_factory, forced, monkeypatch):
+    """The metalness and the reflectivity pass of a half-metallic surface follow one ray; the tracer walks the tree once for
+    both unless SRT_NO_SHARED_QUERIES is set.  Same picture, same ray counts either way."""
+    spec = deep_tree_spec()
+    w, h = 96, 54
+    r = gpu_renderer_factory()
+    r.set_scene(*spec.host(w, h), world_kind=srt.WORLD_SURFACELIST)
+    shared = r.render(w, h, samples=2, max_depth=8, seed=9)
+    st_shared = r.stats()
+    monkeypatch.setenv("SRT_NO_SHARED_QUERIES", "1")
+    each = r.render(w, h, samples=2, max_depth=8, seed=9)
+    st_each = r.stats()
+    r.close()
+    assert np.array_equal(shared, each)
+    assert st_shared["wavefront_twins"] > 0 and st_each["wavefront_twins"] == 0
+    for k in ("rays_path", "rays_shadow", "hit_nodes", "wavefront_items"):
+        assert st_shared[k] == st_each[k], k
